@@ -1,0 +1,81 @@
+"""ctypes binding of the C-ABI HIP library (`include/dcc.h`).
+
+The product path has no CPU fallback: if `libdcc_hip.so` is missing or a kernel returns an
+error code, this raises. Tensors cross the boundary as raw device pointers + sizes + the
+current HIP stream; nothing in the signatures is a torch type.
+"""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+import torch
+
+LIB_PATH = Path(__file__).resolve().parent / "libdcc_hip.so"
+
+DCC_F32, DCC_BF16 = 0, 1
+_ERR = {-1: "DCC_ERR_ARG", -2: "DCC_ERR_LAUNCH", -3: "DCC_ERR_UNSUPPORTED"}
+
+
+class DccError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+c_p, c_i, c_l, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> argtypes; every entry must be declared in include/dcc.h (tests check both directions)
+SIGNATURES: dict[str, list] = {
+    "dcc_version": [],
+    "dcc_gemm": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_f,
+                 c_i, c_i, c_i, c_i, c_i, c_p],
+}
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not LIB_PATH.exists():
+            raise DccError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (there is no CPU fallback on the product path)."
+            )
+        _LIB = ctypes.CDLL(str(LIB_PATH))
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(_LIB, name)
+            fn.argtypes = argtypes
+            fn.restype = c_i
+    return _LIB
+
+
+def dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.float32:
+        return DCC_F32
+    if d == torch.bfloat16:
+        return DCC_BF16
+    raise DccError(f"unsupported dtype {d}")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DccError("deepcoro_clip_amd ops run on the MI355X HIP path only: got a CPU tensor "
+                           "(there is no CPU fallback; the CPU oracle lives under oracle/ for tests)")
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise DccError(f"{name} failed with {_ERR.get(rc, rc)}")

@@ -1,0 +1,569 @@
+// Flash-style multi-head attention for gfx950: forward, dQ and dK/dV kernels.
+//
+//   z[q][k] = scale * <Qf[q], Kf[k]> + kbias[k];  P = softmax_k(z);  O = P V (+ Qres residual)
+//
+// Qf/Kf are DQK wide, V/O are DV wide.  MViT's decomposed relative-position bias is folded into
+// the contraction: Qf = [q | tab(q)/scale], Kf = [k | one-hot(k_t,k_h,k_w)], so the bias costs
+// (DQK-96)/16 extra MFMA K-steps and no gather (see relpos.hip).  The score matrix is never
+// written to HBM; only LSE[q] is kept for the backward.
+//
+// All three kernels compute the TRANSPOSED score tile  S^T = Kf Qf^T  (keys on accumulator
+// rows, queries on lanes) or S (queries on rows, keys on lanes) so that the softmax statistics
+// are per-lane scalars and the probability tile feeds the next MFMA straight from the
+// accumulator registers (cdna guide: "accumulator tile as the next MFMA's operand").
+#include "common.h"
+
+struct AttnParams {
+  const void* Q; const void* K; const void* V; void* O;
+  float* LSE;            // [B,H,Nq] natural-log sum-exp of z
+  const float* kbias;    // [B,Nk] additive key bias (e.g. padding mask) or null
+  const void* Qres;      // residual source with Q's strides (adds Qres[q][0:DV] to O for q >= res_start) or null
+  // backward only
+  const void* dO; const float* Dv;   // Dv[B,H,Nq] = rowsum(dO * O_attn)
+  void* dQ; void* dK; void* dV;      // dK/dV: T when qsplit==1 else fp32 (atomicAdd, pre-zeroed)
+  int64_t sqb, sqn, sqh, skb, skn, skh, svb, svn, svh, sob, son, soh;
+  int64_t sdqb, sdqn, sdqh, sdkb, sdkn, sdkh, sdvb, sdvn, sdvh;
+  int B, H, Nq, Nk;
+  float scale;
+  int res_start;
+  int qsplit;
+};
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr int ANT = 256;  // threads per block
+constexpr int TK = 64;    // rows staged per LDS tile
+
+template <typename T, int D> struct RowTile {  // [rows][D] tile with padded pitch
+  static constexpr int ES = sizeof(T);
+  static constexpr int CH = 16 / ES;
+  static constexpr int PITCH = D * ES + 16;
+  static constexpr int CPR = D / CH;
+};
+
+// cooperative global -> LDS copy of `nrows` rows (zero-filled beyond n_valid)
+template <typename T, int D>
+__device__ __forceinline__ void stage_rows(char* lds, const T* base, int64_t row_stride, int row0, int n_valid,
+                                           int nrows, int tid) {
+  using RT = RowTile<T, D>;
+  using V = vec16_t<T>;
+  const int total = nrows * RT::CPR;
+  for (int id = tid; id < total; id += ANT) {
+    const int r = id / RT::CPR, c = id % RT::CPR;
+    V v;
+#pragma unroll
+    for (int e = 0; e < RT::CH; ++e) v[e] = (T)0.0f;
+    if (row0 + r < n_valid) v = *reinterpret_cast<const V*>(base + (int64_t)(row0 + r) * row_stride + c * RT::CH);
+    *reinterpret_cast<V*>(lds + r * RT::PITCH + c * 16) = v;
+  }
+}
+
+// fragment from global memory: lane (r,h) takes 8 elements at row (row0 + r), cols 16*s + 8*h ..
+template <typename T>
+__device__ __forceinline__ frag_t<T> gfrag(const T* base, int64_t row_stride, int row, int n_valid, int s, int h) {
+  frag_t<T> f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (T)0.0f;
+  if (row < n_valid) {
+    const T* p = base + (int64_t)row * row_stride + 16 * s + 8 * h;
+    if constexpr (sizeof(T) == 2) {
+      f = *reinterpret_cast<const bf16x8*>(p);
+    } else {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
+      f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+      f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    }
+  }
+  return f;
+}
+
+// row-read fragment from a RowTile: lane (r,h): tile row (t0 + r), cols 16*s + 8*h .. +7
+template <typename T, int D>
+__device__ __forceinline__ frag_t<T> row_frag(const char* lds, int t0, int s, int lane) {
+  using RT = RowTile<T, D>;
+  const int r = lane & 31, h = lane >> 5;
+  const char* p = lds + (t0 + r) * RT::PITCH + (16 * s + 8 * h) * RT::ES;
+  frag_t<T> f;
+  if constexpr (sizeof(T) == 2) {
+    f = *reinterpret_cast<const bf16x8*>(p);
+  } else {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(p + 16);
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  }
+  return f;
+}
+
+// transposed fragment matching acc_as_frag's k order: element j of lane (r,h) =
+//   tile[row = t0 + 16*s2 + 8*(j>>2) + 4*h + (j&3)][col = c0 + r]
+template <typename T, int D>
+__device__ __forceinline__ frag_t<T> tr_frag(const char* lds, int t0, int s2, int c0, int lane) {
+  using RT = RowTile<T, D>;
+  const int r = lane & 31, h = lane >> 5;
+  frag_t<T> f;
+  if constexpr (sizeof(T) == 2) {
+    const int i = lane & 15, q = i >> 2, pp = i & 3, g = (lane >> 4) & 1;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int row = t0 + 16 * s2 + 8 * half + 4 * h + q;
+      const char* p = lds + row * RT::PITCH + (c0 + 16 * g + 4 * pp) * 2;
+      const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
+      const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+      f[4 * half + 0] = tb[0]; f[4 * half + 1] = tb[1]; f[4 * half + 2] = tb[2]; f[4 * half + 3] = tb[3];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = t0 + 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3);
+      f[j] = *reinterpret_cast<const float*>(lds + row * RT::PITCH + (c0 + r) * 4);
+    }
+  }
+  return f;
+}
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
+
+// store a transposed accumulator tile: value for (row = n, col = 32*t + acc_row(reg,h)) lives in
+// acc[reg] of the lane with (lane&31) == n - n0.  4 consecutive regs = 4 consecutive columns.
+template <typename T>
+__device__ __forceinline__ void store_tile_T(T* rowptr, int t, int h, const f32x16& acc, float mul,
+                                             const T* resptr) {
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int col = 32 * t + 8 * g4 + 4 * h;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = acc[4 * g4 + e] * mul;
+    if (resptr) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += to_f32(resptr[col + e]);
+    }
+    if constexpr (sizeof(T) == 2) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+      *reinterpret_cast<bf16x4*>(rowptr + col) = o;
+    } else {
+      f32x4 o = {v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(rowptr + col) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: one wave = 32 queries, block = 128 queries; keys/values staged 64 rows at a time.
+template <typename T, int DQK, int DV>
+__global__ __launch_bounds__(ANT) void attn_fwd_kernel(AttnParams p) {
+  using KT = RowTile<T, DQK>;
+  using VT = RowTile<T, DV>;
+  __shared__ __attribute__((aligned(16))) char smem[TK * KT::PITCH + TK * VT::PITCH + TK * 4];
+  char* ldsK = smem;
+  char* ldsV = smem + TK * KT::PITCH;
+  float* ldsB = reinterpret_cast<float*>(smem + TK * KT::PITCH + TK * VT::PITCH);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int myq = q0 + (lane & 31);
+  const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.sqb + hd * p.sqh;
+  const T* K = reinterpret_cast<const T*>(p.K) + b * p.skb + hd * p.skh;
+  const T* V = reinterpret_cast<const T*>(p.V) + b * p.svb + hd * p.svh;
+
+  frag_t<T> qf[DQK / 16];
+#pragma unroll
+  for (int s = 0; s < DQK / 16; ++s) qf[s] = gfrag<T>(Q, p.sqn, myq, p.Nq, s, h);
+
+  f32x16 oacc[DV / 32];
+#pragma unroll
+  for (int t = 0; t < DV / 32; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[t][e] = 0.0f;
+  float m = -INFINITY, l = 0.0f;
+  const float scale2 = p.scale * LOG2E;
+
+  for (int kt0 = 0; kt0 < p.Nk; kt0 += TK) {
+    __syncthreads();
+    stage_rows<T, DQK>(ldsK, K, p.skn, kt0, p.Nk, TK, tid);
+    stage_rows<T, DV>(ldsV, V, p.svn, kt0, p.Nk, TK, tid);
+    if (tid < TK) {
+      const int key = kt0 + tid;
+      float bv = -INFINITY;
+      if (key < p.Nk) bv = p.kbias ? p.kbias[(int64_t)b * p.Nk + key] * LOG2E : 0.0f;
+      ldsB[tid] = bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < TK / 32; ++sub) {
+      if (kt0 + 32 * sub >= p.Nk) break;
+      f32x16 S;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) S[e] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < DQK / 16; ++s) S = mma16(row_frag<T, DQK>(ldsK, 32 * sub, s, lane), qf[s], S);
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        S[e] = S[e] * scale2 + ldsB[32 * sub + acc_row(e, h)];
+        tmax = fmaxf(tmax, S[e]);
+      }
+      tmax = fmaxf(tmax, xhalf(tmax));
+      const float mnew = fmaxf(m, tmax);
+      const float msafe = (mnew == -INFINITY) ? 0.0f : mnew;
+      const float alpha = exp2f(m - msafe);  // m = -inf -> 0
+      float rs = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        S[e] = exp2f(S[e] - msafe);
+        rs += S[e];
+      }
+      rs += xhalf(rs);
+      l = l * alpha + rs;
+      m = mnew;
+#pragma unroll
+      for (int t = 0; t < DV / 32; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[t][e] *= alpha;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const frag_t<T> pf = acc_as_frag<T>(S, s2);
+#pragma unroll
+        for (int t = 0; t < DV / 32; ++t)
+          oacc[t] = mma16(tr_frag<T, DV>(ldsV, 32 * sub, s2, 32 * t, lane), pf, oacc[t]);
+      }
+    }
+  }
+
+  if (myq < p.Nq) {
+    const float inv = (l > 0.0f) ? 1.0f / l : 0.0f;
+    T* orow = reinterpret_cast<T*>(p.O) + b * p.sob + hd * p.soh + (int64_t)myq * p.son;
+    const T* rrow = nullptr;
+    if (p.Qres && myq >= p.res_start)
+      rrow = reinterpret_cast<const T*>(p.Qres) + b * p.sqb + hd * p.sqh + (int64_t)myq * p.sqn;
+#pragma unroll
+    for (int t = 0; t < DV / 32; ++t) store_tile_T<T>(orow, t, h, oacc[t], inv, rrow);
+    if (h == 0 && p.LSE) p.LSE[((int64_t)b * p.H + hd) * p.Nq + myq] = (m + log2f(l)) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dQ: same decomposition as the forward (queries on lanes).
+template <typename T, int DQK, int DV>
+__global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
+  using KT = RowTile<T, DQK>;
+  using VT = RowTile<T, DV>;
+  __shared__ __attribute__((aligned(16))) char smem[TK * KT::PITCH + TK * VT::PITCH + TK * 4];
+  char* ldsK = smem;
+  char* ldsV = smem + TK * KT::PITCH;
+  float* ldsB = reinterpret_cast<float*>(smem + TK * KT::PITCH + TK * VT::PITCH);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int myq = q0 + (lane & 31);
+  const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.sqb + hd * p.sqh;
+  const T* K = reinterpret_cast<const T*>(p.K) + b * p.skb + hd * p.skh;
+  const T* V = reinterpret_cast<const T*>(p.V) + b * p.svb + hd * p.svh;
+  const T* dO = reinterpret_cast<const T*>(p.dO) + b * p.sob + hd * p.soh;
+
+  frag_t<T> qf[DQK / 16], dof[DV / 16];
+#pragma unroll
+  for (int s = 0; s < DQK / 16; ++s) qf[s] = gfrag<T>(Q, p.sqn, myq, p.Nq, s, h);
+#pragma unroll
+  for (int s = 0; s < DV / 16; ++s) dof[s] = gfrag<T>(dO, p.son, myq, p.Nq, s, h);
+  float lse2 = INFINITY, dv = 0.0f;
+  if (myq < p.Nq) {
+    const int64_t o = ((int64_t)b * p.H + hd) * p.Nq + myq;
+    lse2 = p.LSE[o] * LOG2E;
+    dv = p.Dv[o];
+  }
+  f32x16 dq[DQK / 32];
+#pragma unroll
+  for (int t = 0; t < DQK / 32; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[t][e] = 0.0f;
+  const float scale2 = p.scale * LOG2E;
+
+  for (int kt0 = 0; kt0 < p.Nk; kt0 += TK) {
+    __syncthreads();
+    stage_rows<T, DQK>(ldsK, K, p.skn, kt0, p.Nk, TK, tid);
+    stage_rows<T, DV>(ldsV, V, p.svn, kt0, p.Nk, TK, tid);
+    if (tid < TK) {
+      const int key = kt0 + tid;
+      float bv = -INFINITY;
+      if (key < p.Nk) bv = p.kbias ? p.kbias[(int64_t)b * p.Nk + key] * LOG2E : 0.0f;
+      ldsB[tid] = bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < TK / 32; ++sub) {
+      if (kt0 + 32 * sub >= p.Nk) break;
+      f32x16 S, dP;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { S[e] = 0.0f; dP[e] = 0.0f; }
+#pragma unroll
+      for (int s = 0; s < DQK / 16; ++s) S = mma16(row_frag<T, DQK>(ldsK, 32 * sub, s, lane), qf[s], S);
+#pragma unroll
+      for (int s = 0; s < DV / 16; ++s) dP = mma16(row_frag<T, DV>(ldsV, 32 * sub, s, lane), dof[s], dP);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pr = exp2f(S[e] * scale2 + ldsB[32 * sub + acc_row(e, h)] - lse2);
+        S[e] = pr * (dP[e] - dv);  // dz^T
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const frag_t<T> zf = acc_as_frag<T>(S, s2);
+#pragma unroll
+        for (int t = 0; t < DQK / 32; ++t)
+          dq[t] = mma16(tr_frag<T, DQK>(ldsK, 32 * sub, s2, 32 * t, lane), zf, dq[t]);
+      }
+    }
+  }
+  if (myq < p.Nq) {
+    T* drow = reinterpret_cast<T*>(p.dQ) + b * p.sdqb + hd * p.sdqh + (int64_t)myq * p.sdqn;
+#pragma unroll
+    for (int t = 0; t < DQK / 32; ++t) store_tile_T<T>(drow, t, h, dq[t], p.scale, nullptr);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dK/dV: keys on lanes (one wave = 32 keys, block = 128 keys), queries staged 64 rows at a time.
+// blockIdx.x = key block * qsplit + query split.
+template <typename T, typename TO, int DQK, int DV>
+__global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
+  using QT = RowTile<T, DQK>;
+  using OT = RowTile<T, DV>;
+  __shared__ __attribute__((aligned(16))) char smem[TK * QT::PITCH + TK * OT::PITCH + 2 * TK * 4];
+  char* ldsQ = smem;
+  char* ldsO = smem + TK * QT::PITCH;
+  float* ldsL = reinterpret_cast<float*>(smem + TK * QT::PITCH + TK * OT::PITCH);
+  float* ldsD = ldsL + TK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int kblk = blockIdx.x / p.qsplit, qs = blockIdx.x % p.qsplit;
+  const int k0 = kblk * 128 + wave * 32;
+  const int mykey = k0 + (lane & 31);
+  const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.sqb + hd * p.sqh;
+  const T* K = reinterpret_cast<const T*>(p.K) + b * p.skb + hd * p.skh;
+  const T* V = reinterpret_cast<const T*>(p.V) + b * p.svb + hd * p.svh;
+  const T* dO = reinterpret_cast<const T*>(p.dO) + b * p.sob + hd * p.soh;
+  const float* LSE = p.LSE + ((int64_t)b * p.H + hd) * p.Nq;
+  const float* Dv = p.Dv + ((int64_t)b * p.H + hd) * p.Nq;
+
+  frag_t<T> kf[DQK / 16], vf[DV / 16];
+#pragma unroll
+  for (int s = 0; s < DQK / 16; ++s) kf[s] = gfrag<T>(K, p.skn, mykey, p.Nk, s, h);
+#pragma unroll
+  for (int s = 0; s < DV / 16; ++s) vf[s] = gfrag<T>(V, p.svn, mykey, p.Nk, s, h);
+  float kb2 = -INFINITY;
+  if (mykey < p.Nk) kb2 = p.kbias ? p.kbias[(int64_t)b * p.Nk + mykey] * LOG2E : 0.0f;
+
+  f32x16 dk[DQK / 32], dvv[DV / 32];
+#pragma unroll
+  for (int t = 0; t < DQK / 32; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dk[t][e] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < DV / 32; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dvv[t][e] = 0.0f;
+  const float scale2 = p.scale * LOG2E;
+
+  // query range of this split, in units of TK rows
+  const int qtiles = (p.Nq + TK - 1) / TK;
+  const int per = (qtiles + p.qsplit - 1) / p.qsplit;
+  const int qt_begin = qs * per;
+  int qt_end = qt_begin + per; if (qt_end > qtiles) qt_end = qtiles;
+
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    const int qq0 = qt * TK;
+    __syncthreads();
+    stage_rows<T, DQK>(ldsQ, Q, p.sqn, qq0, p.Nq, TK, tid);
+    stage_rows<T, DV>(ldsO, dO, p.son, qq0, p.Nq, TK, tid);
+    if (tid < TK) {
+      const int q = qq0 + tid;
+      ldsL[tid] = (q < p.Nq) ? LSE[q] * LOG2E : INFINITY;
+      ldsD[tid] = (q < p.Nq) ? Dv[q] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < TK / 32; ++sub) {
+      if (qq0 + 32 * sub >= p.Nq) break;
+      f32x16 S, dP;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { S[e] = 0.0f; dP[e] = 0.0f; }
+#pragma unroll
+      for (int s = 0; s < DQK / 16; ++s) S = mma16(row_frag<T, DQK>(ldsQ, 32 * sub, s, lane), kf[s], S);
+#pragma unroll
+      for (int s = 0; s < DV / 16; ++s) dP = mma16(row_frag<T, DV>(ldsO, 32 * sub, s, lane), vf[s], dP);
+      // rows = queries, lanes = keys
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int qi = 32 * sub + acc_row(e, h);
+        const float pr = exp2f(S[e] * scale2 + kb2 - ldsL[qi]);
+        S[e] = pr;                        // P
+        dP[e] = pr * (dP[e] - ldsD[qi]);  // dz
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const frag_t<T> pf = acc_as_frag<T>(S, s2);
+        const frag_t<T> zf = acc_as_frag<T>(dP, s2);
+#pragma unroll
+        for (int t = 0; t < DV / 32; ++t)
+          dvv[t] = mma16(tr_frag<T, DV>(ldsO, 32 * sub, s2, 32 * t, lane), pf, dvv[t]);
+#pragma unroll
+        for (int t = 0; t < DQK / 32; ++t)
+          dk[t] = mma16(tr_frag<T, DQK>(ldsQ, 32 * sub, s2, 32 * t, lane), zf, dk[t]);
+      }
+    }
+  }
+
+  if (mykey < p.Nk) {
+    TO* dkrow = reinterpret_cast<TO*>(p.dK) + b * p.sdkb + hd * p.sdkh + (int64_t)mykey * p.sdkn;
+    TO* dvrow = reinterpret_cast<TO*>(p.dV) + b * p.sdvb + hd * p.sdvh + (int64_t)mykey * p.sdvn;
+    if (p.qsplit == 1) {
+#pragma unroll
+      for (int t = 0; t < DQK / 32; ++t) store_tile_T<TO>(dkrow, t, h, dk[t], p.scale, nullptr);
+#pragma unroll
+      for (int t = 0; t < DV / 32; ++t) store_tile_T<TO>(dvrow, t, h, dvv[t], 1.0f, nullptr);
+    } else if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+      for (int t = 0; t < DQK / 32; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          atomicAdd(reinterpret_cast<float*>(dkrow) + 32 * t + acc_row(e, h), dk[t][e] * p.scale);
+#pragma unroll
+      for (int t = 0; t < DV / 32; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) atomicAdd(reinterpret_cast<float*>(dvrow) + 32 * t + acc_row(e, h), dvv[t][e]);
+    }
+  }
+}
+
+// Dv[b,h,q] = sum_d dO[q][d] * (O[q][d] - [q >= res_start] Qres[q][d]); one wave per (b,h,q) row.
+template <typename T>
+__global__ void attn_bwd_prep_kernel(AttnParams p, int DV) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t total = (int64_t)p.B * p.H * p.Nq;
+  if (row >= total) return;
+  const int q = row % p.Nq;
+  const int hd = (row / p.Nq) % p.H;
+  const int b = row / ((int64_t)p.Nq * p.H);
+  const T* o = reinterpret_cast<const T*>(p.O) + b * p.sob + hd * p.soh + (int64_t)q * p.son;
+  const T* d = reinterpret_cast<const T*>(p.dO) + b * p.sob + hd * p.soh + (int64_t)q * p.son;
+  const T* r = (p.Qres && q >= p.res_start)
+                   ? reinterpret_cast<const T*>(p.Qres) + b * p.sqb + hd * p.sqh + (int64_t)q * p.sqn
+                   : nullptr;
+  float acc = 0.0f;
+  for (int c = lane; c < DV; c += 64) {
+    float ov = to_f32(o[c]);
+    if (r) ov -= to_f32(r[c]);
+    acc += to_f32(d[c]) * ov;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) const_cast<float*>(p.Dv)[row] = acc;
+}
+
+template <typename T, int DQK, int DV>
+int launch_attn(int which, const AttnParams& p, int out_f32, hipStream_t st) {
+  if (which == 0) {
+    dim3 grid((p.Nq + 127) / 128, p.H, p.B);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DQK, DV>), grid, dim3(ANT), 0, st, p);
+  } else if (which == 1) {
+    dim3 grid((p.Nq + 127) / 128, p.H, p.B);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DQK, DV>), grid, dim3(ANT), 0, st, p);
+  } else {
+    dim3 grid(((p.Nk + 127) / 128) * p.qsplit, p.H, p.B);
+    if (out_f32) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, float, DQK, DV>), grid, dim3(ANT), 0, st, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, T, DQK, DV>), grid, dim3(ANT), 0, st, p);
+  }
+  return dcc_check_launch();
+}
+
+template <typename T>
+int dispatch_dims(int which, const AttnParams& p, int dqk, int dv, int out_f32, hipStream_t st) {
+  if (dqk == 64 && dv == 64) return launch_attn<T, 64, 64>(which, p, out_f32, st);
+  if (dqk == 96 && dv == 96) return launch_attn<T, 96, 96>(which, p, out_f32, st);
+  if (dqk == 128 && dv == 96) return launch_attn<T, 128, 96>(which, p, out_f32, st);
+  if (dqk == 160 && dv == 96) return launch_attn<T, 160, 96>(which, p, out_f32, st);
+  if (dqk == 128 && dv == 128) return launch_attn<T, 128, 128>(which, p, out_f32, st);
+  return DCC_ERR_UNSUPPORTED;
+}
+
+int check_common(const AttnParams& p, int dtype) {
+  if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) return DCC_ERR_ARG;
+  if (p.H > 65535 || p.B > 65535) return DCC_ERR_ARG;
+  const int ch = dtype == DCC_BF16 ? 8 : 4;
+  const int64_t strides[] = {p.sqb, p.sqn, p.sqh, p.skb, p.skn, p.skh, p.svb, p.svn, p.svh, p.sob, p.son, p.soh};
+  for (int64_t s : strides)
+    if (s % ch) return DCC_ERR_UNSUPPORTED;
+  if (((uintptr_t)p.Q & 15) || ((uintptr_t)p.K & 15) || ((uintptr_t)p.V & 15) || ((uintptr_t)p.O & 15))
+    return DCC_ERR_UNSUPPORTED;
+  return DCC_OK;
+}
+
+}  // namespace
+
+extern "C" int dcc_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, const float* kbias,
+                            const void* Qres, int res_start, const int64_t* strides /*12: q,k,v,o x (b,n,h)*/, int B,
+                            int H, int Nq, int Nk, int DQK, int DV, float scale, int dtype, void* stream) {
+  if (!Q || !K || !V || !O || !strides) return DCC_ERR_ARG;
+  AttnParams p{};
+  p.Q = Q; p.K = K; p.V = V; p.O = O; p.LSE = LSE; p.kbias = kbias; p.Qres = Qres; p.res_start = res_start;
+  p.sqb = strides[0]; p.sqn = strides[1]; p.sqh = strides[2];
+  p.skb = strides[3]; p.skn = strides[4]; p.skh = strides[5];
+  p.svb = strides[6]; p.svn = strides[7]; p.svh = strides[8];
+  p.sob = strides[9]; p.son = strides[10]; p.soh = strides[11];
+  p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = 1;
+  int rc = check_common(p, dtype);
+  if (rc) return rc;
+  if (dtype == DCC_BF16) return dispatch_dims<bf16_t>(0, p, DQK, DV, 0, (hipStream_t)stream);
+  if (dtype == DCC_F32) return dispatch_dims<float>(0, p, DQK, DV, 0, (hipStream_t)stream);
+  return DCC_ERR_UNSUPPORTED;
+}
+
+// Backward. Dv is workspace [B,H,Nq] fp32 (written here).  dK/dV are T when qsplit == 1, else fp32
+// buffers that the caller has zeroed (atomic accumulation over query splits).
+extern "C" int dcc_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                            const float* LSE, float* Dv, const float* kbias, const void* Qres, int res_start, void* dQ,
+                            void* dK, void* dV, const int64_t* strides /*21: q,k,v,o,dq,dk,dv x (b,n,h)*/, int B, int H,
+                            int Nq, int Nk, int DQK, int DV, float scale, int qsplit, int dtype, void* stream) {
+  if (!Q || !K || !V || !O || !dO || !LSE || !Dv || !dQ || !dK || !dV || !strides) return DCC_ERR_ARG;
+  if (qsplit < 1) return DCC_ERR_ARG;
+  AttnParams p{};
+  p.Q = Q; p.K = K; p.V = V; p.O = const_cast<void*>(O); p.dO = dO; p.LSE = const_cast<float*>(LSE); p.Dv = Dv;
+  p.kbias = kbias; p.Qres = Qres; p.res_start = res_start; p.dQ = dQ; p.dK = dK; p.dV = dV;
+  p.sqb = strides[0]; p.sqn = strides[1]; p.sqh = strides[2];
+  p.skb = strides[3]; p.skn = strides[4]; p.skh = strides[5];
+  p.svb = strides[6]; p.svn = strides[7]; p.svh = strides[8];
+  p.sob = strides[9]; p.son = strides[10]; p.soh = strides[11];
+  p.sdqb = strides[12]; p.sdqn = strides[13]; p.sdqh = strides[14];
+  p.sdkb = strides[15]; p.sdkn = strides[16]; p.sdkh = strides[17];
+  p.sdvb = strides[18]; p.sdvn = strides[19]; p.sdvh = strides[20];
+  p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = qsplit;
+  int rc = check_common(p, dtype);
+  if (rc) return rc;
+  for (int i = 12; i < 21; ++i)
+    if (strides[i] % 4) return DCC_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * H * Nq;
+  const int wpb = 4;
+  dim3 pg((unsigned)((rows + wpb - 1) / wpb));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((attn_bwd_prep_kernel<bf16_t>), pg, dim3(64 * wpb), 0, st, p, DV);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((attn_bwd_prep_kernel<float>), pg, dim3(64 * wpb), 0, st, p, DV);
+  else return DCC_ERR_UNSUPPORTED;
+  rc = dcc_check_launch();
+  if (rc) return rc;
+  const int out_f32 = (qsplit > 1) || dtype == DCC_F32;
+  for (int which = 1; which <= 2; ++which) {
+    if (dtype == DCC_BF16) rc = dispatch_dims<bf16_t>(which, p, DQK, DV, out_f32, st);
+    else rc = dispatch_dims<float>(which, p, DQK, DV, out_f32, st);
+    if (rc) return rc;
+  }
+  return DCC_OK;
+}

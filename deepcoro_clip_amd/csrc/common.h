@@ -1,0 +1,107 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the DeepCORO_CLIP hot path.
+// Wave = 64 lanes. All matrix work uses v_mfma_f32_32x32x16_bf16 (bf16 operands) or
+// v_mfma_f32_32x32x2_f32 (exact fp32 operands) behind one 8-element fragment abstraction:
+//   lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j], B[k = 8h + j][col r], j = 0..7
+// for one K=16 step.  For bf16 that is one MFMA instruction, for fp32 eight 32x32x2
+// instructions (instruction j pairs k = j of half 0 with k = 8 + j of half 1), so the
+// fragment images in LDS / registers are identical for both element types.
+// C/D layout of a 32x32 tile: col = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DCC_OK 0
+#define DCC_ERR_ARG -1
+#define DCC_ERR_LAUNCH -2
+#define DCC_ERR_UNSUPPORTED -3
+
+// dtype codes of the C ABI
+#define DCC_F32 0
+#define DCC_BF16 1
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+template <typename T> struct Frag;  // 8-element MFMA operand fragment
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<float> { typedef f32x8 type; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// One K=16 MFMA step on 32x32 tiles.
+__device__ __forceinline__ f32x16 mma16(const bf16x8& a, const bf16x8& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma16(const f32x8& a, const f32x8& b, f32x16 c) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+  return c;
+}
+
+// Accumulator registers 8*s .. 8*s+7 of a 32x32 tile as the fragment of K-step s of a following
+// MFMA that sums over the tile's ROW index (cdna guide: accumulator tile as next operand).
+// Element j of lane half h is row 16*s + 8*(j>>2) + 4*h + (j&3) of the tile.
+template <typename T> __device__ __forceinline__ typename Frag<T>::type acc_as_frag(const f32x16& x, int s);
+template <> __device__ __forceinline__ bf16x8 acc_as_frag<bf16_t>(const f32x16& x, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16_t)x[8 * s + j];
+  return r;
+}
+template <> __device__ __forceinline__ f32x8 acc_as_frag<float>(const f32x16& x, int s) {
+  f32x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = x[8 * s + j];
+  return r;
+}
+
+// Row of accumulator register `reg` for lane half h.
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// 16-byte vector helpers -------------------------------------------------------------------
+template <typename T> struct Vec16;  // the 16-byte global/LDS access unit
+template <> struct Vec16<bf16_t> { typedef bf16x8 type; static constexpr int N = 8; };
+template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4; };
+
+template <typename T> using vec16_t = typename Vec16<T>::type;
+template <typename T> using frag_t = typename Frag<T>::type;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_f(float x) {  // exact erf GELU (nn.GELU default)
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline int dcc_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DCC_OK : DCC_ERR_LAUNCH;
+}

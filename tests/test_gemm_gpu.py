@@ -1,0 +1,71 @@
+"""HIP MFMA GEMM (csrc/gemm.hip) vs a plain PyTorch fp32 reference, through the C ABI."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(a, b, a_km, b_km):
+    A = a.float().t() if a_km else a.float()
+    B = b.float().t() if b_km else b.float()
+    return A.double() @ B.double().t()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("a_km,b_km", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 96, 96), (393, 288, 192), (1000, 136, 64), (24, 24, 512)])
+def test_gemm_layouts(dtype, a_km, b_km, M, N, K):
+    from deepcoro_clip_amd import kernels as Kx
+
+    if (a_km and M % 8) or (b_km and N % 8):
+        pytest.skip("k-major operands need 16-byte multiples in the contiguous dim")
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((K, M) if a_km else (M, K), generator=g).to("cuda", dtype)
+    b = torch.randn((K, N) if b_km else (N, K), generator=g).to("cuda", dtype)
+    out = Kx.gemm(a, b, a_km=a_km, b_km=b_km, out_dtype=torch.float32)
+    ref = _ref(a, b, a_km, b_km)
+    # integer-exact check of the fragment maps first (small ints are exact in bf16 and fp32)
+    ai = torch.randint(-3, 4, a.shape, generator=g).to("cuda", dtype)
+    bi = torch.randint(-3, 4, b.shape, generator=g).to("cuda", dtype)
+    outi = Kx.gemm(ai, bi, a_km=a_km, b_km=b_km, out_dtype=torch.float32)
+    assert torch.equal(outi.double(), _ref(ai, bi, a_km, b_km)), "fragment layout mismatch (exact integer data)"
+    tol = 1e-4 if dtype == torch.float32 else 1e-5  # bf16 inputs are exact; accumulation is fp32 in both
+    err = (out.double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(dtype):
+    from deepcoro_clip_amd import kernels as Kx
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, N, K = 300, 192, 96
+    a = torch.randn(M, K, generator=g).to("cuda", dtype)
+    w = (torch.randn(N, K, generator=g) * 0.1).to("cuda", dtype)
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to("cuda", dtype)
+    pre = torch.empty(M, N, device="cuda", dtype=dtype)
+    out = Kx.gemm(a, w, bias=bias, gelu=True, save_pre=True, aux=pre, resid=res)
+    ref_pre = a.float() @ w.float().t() + bias
+    ref = torch.nn.functional.gelu(ref_pre) + res.float()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (pre.float() - ref_pre).abs().max() < tol * max(1.0, ref_pre.abs().max().item())
+    assert (out.float() - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
+    # dgelu epilogue: out = (a @ w^T) * gelu'(pre)
+    out2 = Kx.gemm(a, w, dgelu=True, aux=pre)
+    x = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    ref2 = (a.float() @ w.float().t()) * x.grad
+    assert (out2.float() - ref2).abs().max() < tol * max(1.0, ref2.abs().max().item())
+
+
+def test_gemm_splitk_accumulate():
+    from deepcoro_clip_amd import kernels as Kx
+
+    g = torch.Generator(device="cpu").manual_seed(9)
+    Mred, N, K = 5000, 96, 288  # weight-gradient shape: reduce over many rows
+    dy = torch.randn(Mred, N, generator=g).to("cuda", torch.bfloat16)
+    x = torch.randn(Mred, K, generator=g).to("cuda", torch.bfloat16)
+    out = Kx.gemm(dy, x, a_km=True, b_km=True, out_dtype=torch.float32, splitk=8)
+    ref = dy.float().t().double() @ x.float().double()
+    assert (out.double() - ref).abs().max() < 1e-3 * ref.abs().max()
