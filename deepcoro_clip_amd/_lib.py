@@ -30,6 +30,9 @@ SIGNATURES: dict[str, list] = {
     "dcc_version": [],
     "dcc_gemm": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_f,
                  c_i, c_i, c_i, c_i, c_i, c_p],
+    "dcc_attn_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
+    "dcc_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
+                     c_f, c_i, c_i, c_p],
 }
 
 

@@ -53,3 +53,53 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
            out.stride(0), resid.stride(0) if resid is not None else 0, aux.stride(0) if aux is not None else 0, M, N, K,
            1, 0, 0, 0, splitk, float(alpha), flags, int(a_km), int(b_km), L.dt(a), L.dt(out), L.stream())
     return out
+
+
+def _strides3(t: torch.Tensor) -> list[int]:
+    assert t.dim() == 4 and t.stride(3) == 1, "attention operands are [B, N, H, D] views with unit inner stride"
+    return [t.stride(0), t.stride(1), t.stride(2)]
+
+
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: float, kbias: torch.Tensor | None = None,
+             residual: bool = False, res_start: int = 0):
+    """O = softmax(scale * q k^T + kbias) v (+ q[..., :DV] for rows >= res_start). Returns (O [B,Nq,H,DV], LSE [B,H,Nq])."""
+    import ctypes
+
+    L.require_cuda(q, k, v, kbias)
+    B, Nq, H, DQK = q.shape
+    Nk, DV = k.shape[1], v.shape[3]
+    assert k.shape == (B, Nk, H, DQK) and v.shape == (B, Nk, H, DV) and q.dtype == k.dtype == v.dtype
+    o = torch.empty((B, Nq, H, DV), device=q.device, dtype=q.dtype)
+    lse = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
+    if kbias is not None:
+        assert kbias.shape == (B, Nk) and kbias.dtype == torch.float32 and kbias.is_contiguous()
+    st = (ctypes.c_int64 * 12)(*(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o)))
+    L.call("dcc_attn_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(kbias),
+           L.ptr(q) if residual else None, int(res_start), st, B, H, Nq, Nk, DQK, DV, float(scale), L.dt(q), L.stream())
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, *, scale: float, kbias=None, residual: bool = False, res_start: int = 0,
+             qsplit: int | None = None):
+    """Gradients of attn_fwd w.r.t. q (attention path only; the residual's dq = do is the caller's), k, v."""
+    import ctypes
+
+    L.require_cuda(q, k, v, o, do, lse)
+    B, Nq, H, DQK = q.shape
+    Nk, DV = k.shape[1], v.shape[3]
+    assert do.shape == o.shape and do.stride() == o.stride(), "dO must share O's layout"
+    if qsplit is None:
+        kblocks = ((Nk + 127) // 128) * H * B
+        qsplit = 1 if kblocks >= 512 else max(1, min((Nq + 63) // 64, (1024 + kblocks - 1) // kblocks))
+    dq = torch.empty((B, Nq, H, DQK), device=q.device, dtype=q.dtype)
+    kv_dtype = torch.float32 if qsplit > 1 else q.dtype
+    alloc = torch.zeros if qsplit > 1 else torch.empty
+    dk = alloc((B, Nk, H, DQK), device=q.device, dtype=kv_dtype)
+    dv = alloc((B, Nk, H, DV), device=q.device, dtype=kv_dtype)
+    dvec = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
+    st = (ctypes.c_int64 * 21)(*(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o) + _strides3(dq) +
+                                 _strides3(dk) + _strides3(dv)))
+    L.call("dcc_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(dvec), L.ptr(kbias),
+           L.ptr(q) if residual else None, int(res_start), L.ptr(dq), L.ptr(dk), L.ptr(dv), st, B, H, Nq, Nk, DQK, DV,
+           float(scale), int(qsplit), L.dt(q), L.stream())
+    return dq, dk, dv
