@@ -23,17 +23,39 @@ class DccError(RuntimeError):
 
 _LIB = None
 
-c_p, c_i, c_l, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+HEADER_PATH = Path(__file__).resolve().parent.parent / "include" / "dcc.h"
 
-# name -> argtypes; every entry must be declared in include/dcc.h (tests check both directions)
-SIGNATURES: dict[str, list] = {
-    "dcc_version": [],
-    "dcc_gemm": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_f,
-                 c_i, c_i, c_i, c_i, c_i, c_p],
-    "dcc_attn_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
-    "dcc_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
-                     c_f, c_i, c_i, c_p],
-}
+
+def _parse_header(path: Path = HEADER_PATH) -> dict[str, list]:
+    """Derive ctypes argtypes from the prototypes in include/dcc.h (single source of truth)."""
+    import re
+
+    text = path.read_text()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    sigs: dict[str, list] = {}
+    for m in re.finditer(r"\bint\s+(dcc_\w+)\s*\(([^)]*)\)\s*;", text):
+        name, args = m.group(1), m.group(2).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                elif a.startswith("int64_t"):
+                    argtypes.append(ctypes.c_int64)
+                elif a.startswith("uint64_t"):
+                    argtypes.append(ctypes.c_uint64)
+                elif a.startswith("float"):
+                    argtypes.append(ctypes.c_float)
+                elif a.startswith("int"):
+                    argtypes.append(ctypes.c_int)
+                else:
+                    raise DccError(f"cannot map C type in '{a}' of {name}")
+        sigs[name] = argtypes
+    return sigs
+
+
+SIGNATURES: dict[str, list] = _parse_header()
 
 
 def lib() -> ctypes.CDLL:
@@ -48,7 +70,7 @@ def lib() -> ctypes.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(_LIB, name)
             fn.argtypes = argtypes
-            fn.restype = c_i
+            fn.restype = ctypes.c_int
     return _LIB
 
 

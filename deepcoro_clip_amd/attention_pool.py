@@ -1,0 +1,40 @@
+"""AttentionPool on HIP kernels (reference: models/attention_pool.py:10-101): a learnable query attends over the
+tokens of one video through nn.MultiheadAttention(batch_first) semantics, then LayerNorm (+ optional Linear)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+
+
+class AttentionPool(nn.Module):
+    def __init__(self, embed_dim: int, num_heads: int = 8, output_dim: int | None = None, dropout: float = 0.0):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.output_dim = output_dim or embed_dim
+        self.query = nn.Parameter(torch.randn(1, 1, embed_dim))
+        nn.init.trunc_normal_(self.query, std=0.02)
+        # parameter container only (in_proj_weight / in_proj_bias / out_proj.*): forward() is never called
+        self.attn = nn.MultiheadAttention(embed_dim=embed_dim, num_heads=num_heads, dropout=dropout, batch_first=True)
+        self.attn_dropout = dropout
+        self.norm = nn.LayerNorm(embed_dim)
+        self.proj = nn.Linear(embed_dim, self.output_dim) if self.output_dim != embed_dim else nn.Identity()
+
+    def forward(self, x: torch.Tensor, mask: torch.Tensor | None = None) -> torch.Tensor:
+        """x: [B, N, D] (compute dtype) -> [B, output_dim]."""
+        if mask is not None:
+            raise NotImplementedError("key_padding_mask is unused on the contrastive path (models/video_encoder.py:597-602)")
+        if self.training and self.attn_dropout > 0:
+            raise NotImplementedError("attention-weight dropout inside AttentionPool is not implemented on the HIP path; "
+                                      "use attention_pool_dropout=0")
+        B, N, D = x.shape
+        assert D == self.embed_dim, f"Input dim {D} != expected {self.embed_dim}"
+        q = Fn.cast(self.query, x.dtype).expand(B, 1, D)
+        a = self.attn
+        o = Fn.multihead_attention(q, x, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                                   self.num_heads, self_attn=False)
+        o = Fn.layernorm(o, self.norm.weight, self.norm.bias, self.norm.eps)
+        if isinstance(self.proj, nn.Linear):
+            o = Fn.linear(o, self.proj.weight, self.proj.bias)
+        return o.reshape(B, -1)

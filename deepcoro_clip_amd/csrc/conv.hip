@@ -1,0 +1,396 @@
+// Convolution-shaped kernels of the MViT path (all HBM-bound, channels-last token layout):
+//   * im2col for the 3-D patch embedding (video NDHWC fp32 -> [tokens, Kp] operand of the MFMA GEMM)
+//   * depthwise 3x3x3 conv pooling of q/k/v heads (forward, data gradient, weight gradient)
+//   * max-pool of the skip path (forward with argmax, backward)
+// Tokens are [B, N, H, C] views (strides in elements, C contiguous); token 0 is the class token
+// when has_cls != 0 and bypasses the pooling; the remaining tokens form a (T, Hs, Ws) grid.
+#include "common.h"
+
+namespace {
+
+struct PoolGeom {
+  int B, H, C;          // batch, heads, channels per head
+  int T, Hs, Ws;        // input grid
+  int To, Ho, Wo;       // output grid
+  int st, sh, sw;       // strides
+  int kt, kh, kw;       // kernel
+  int pt, ph, pw;       // padding
+  int has_cls;
+  int64_t sxb, sxn, sxh;  // input strides
+  int64_t syb, syn, syh;  // output strides
+};
+
+// ---------------------------------------------------------------- patch-embed im2col
+// col[tok][(kt*KH + kh)*KW*Cin + kw*Cin + c], zero padded to Kp; one wave per output token.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int Tn,
+                                                       int Hn, int Wn, int Cin, int KT, int KH, int KW, int st, int sh,
+                                                       int sw, int pt, int ph, int pw, int To, int Ho, int Wo, int Kp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t ntok = (int64_t)B * To * Ho * Wo;
+  if (tok >= ntok) return;
+  const int wo = tok % Wo, ho = (tok / Wo) % Ho, to = (tok / ((int64_t)Wo * Ho)) % To;
+  const int b = tok / ((int64_t)Wo * Ho * To);
+  const int run = KW * Cin;  // contiguous run in the input per (kt, kh)
+  const int K = KT * KH * run;
+  const float* xb = x + (int64_t)b * Tn * Hn * Wn * Cin;
+  T* dst = col + tok * Kp;
+  for (int i = lane; i < Kp; i += 64) {
+    float v = 0.0f;
+    if (i < K) {
+      const int r = i % run, kh = (i / run) % KH, kt = i / (run * KH);
+      const int kw = r / Cin, c = r % Cin;
+      const int t = to * st - pt + kt, hh = ho * sh - ph + kh, ww = wo * sw - pw + kw;
+      if (t >= 0 && t < Tn && hh >= 0 && hh < Hn && ww >= 0 && ww < Wn)
+        v = xb[(((int64_t)t * Hn + hh) * Wn + ww) * Cin + c];
+    }
+    dst[i] = from_f32<T>(v);
+  }
+}
+
+// ---------------------------------------------------------------- depthwise conv / max pool forward
+// one thread = one 16-byte channel chunk of one output token-head.
+template <typename T, bool MAXPOOL>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                       const float* __restrict__ w /*[C][taps]*/,
+                                                       uint8_t* __restrict__ argmax, PoolGeom g) {
+  constexpr int VEC = Vec16<T>::N;
+  using V = vec16_t<T>;
+  extern __shared__ __attribute__((aligned(16))) float wlds[];  // [taps][C]
+  const int taps = g.kt * g.kh * g.kw;
+  if (!MAXPOOL) {
+    for (int i = threadIdx.x; i < taps * g.C; i += blockDim.x) {
+      const int k = i / g.C, c = i % g.C;
+      wlds[i] = w[c * taps + k];
+    }
+    __syncthreads();
+  }
+  const int cpr = g.C / VEC;
+  const int No = g.To * g.Ho * g.Wo + g.has_cls;
+  const int64_t total = (int64_t)g.B * No * g.H * cpr;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+    const int c = id % cpr;
+    const int hd = (id / cpr) % g.H;
+    const int n = (id / ((int64_t)cpr * g.H)) % No;
+    const int b = id / ((int64_t)cpr * g.H * No);
+    const T* xb = x + b * g.sxb + hd * g.sxh + c * VEC;
+    T* yo = y + b * g.syb + (int64_t)n * g.syn + hd * g.syh + c * VEC;
+    if (g.has_cls && n == 0) {
+      *reinterpret_cast<V*>(yo) = *reinterpret_cast<const V*>(xb);
+      if (MAXPOOL && argmax) {
+        uint8_t* am = argmax + ((((int64_t)b * No + n) * g.H + hd) * g.C + c * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) am[e] = 255;
+      }
+      continue;
+    }
+    const int o = n - g.has_cls;
+    const int wo = o % g.Wo, ho = (o / g.Wo) % g.Ho, to = o / (g.Wo * g.Ho);
+    float acc[VEC];
+    int am[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { acc[e] = MAXPOOL ? -INFINITY : 0.0f; am[e] = 255; }
+    for (int kt = 0; kt < g.kt; ++kt) {
+      const int t = to * g.st - g.pt + kt;
+      if (t < 0 || t >= g.T) continue;
+      for (int kh = 0; kh < g.kh; ++kh) {
+        const int hh = ho * g.sh - g.ph + kh;
+        if (hh < 0 || hh >= g.Hs) continue;
+        for (int kw = 0; kw < g.kw; ++kw) {
+          const int ww = wo * g.sw - g.pw + kw;
+          if (ww < 0 || ww >= g.Ws) continue;
+          const int nin = g.has_cls + (t * g.Hs + hh) * g.Ws + ww;
+          const V v = *reinterpret_cast<const V*>(xb + (int64_t)nin * g.sxn);
+          const int tap = (kt * g.kh + kh) * g.kw + kw;
+          if (MAXPOOL) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float f = to_f32(v[e]);
+              if (f > acc[e]) { acc[e] = f; am[e] = tap; }
+            }
+          } else {
+            const float* wk = wlds + tap * g.C + c * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += to_f32(v[e]) * wk[e];
+          }
+        }
+      }
+    }
+    V out;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out[e] = from_f32<T>(acc[e]);
+    *reinterpret_cast<V*>(yo) = out;
+    if (MAXPOOL && argmax) {
+      uint8_t* amp = argmax + ((((int64_t)b * No + n) * g.H + hd) * g.C + c * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) amp[e] = (uint8_t)am[e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- data gradient (gather form)
+// dx[in] = sum over (output o, tap k) with in = o*s - p + k of dy[o] * w[k]   (or dy[o] if argmax[o]==k)
+// x-strides describe dx (the destination, e.g. a slice of the dqkv buffer); y-strides describe dy.
+template <typename T, typename TD, bool MAXPOOL>
+__global__ __launch_bounds__(256) void pool_bwd_data_kernel(const TD* __restrict__ dy, T* __restrict__ dx,
+                                                            const float* __restrict__ w,
+                                                            const uint8_t* __restrict__ argmax, PoolGeom g) {
+  constexpr int VEC = Vec16<T>::N;
+  using V = vec16_t<T>;
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  const int taps = g.kt * g.kh * g.kw;
+  if (!MAXPOOL) {
+    for (int i = threadIdx.x; i < taps * g.C; i += blockDim.x) {
+      const int k = i / g.C, c = i % g.C;
+      wlds[i] = w[c * taps + k];
+    }
+    __syncthreads();
+  }
+  const int cpr = g.C / VEC;
+  const int Ni = g.T * g.Hs * g.Ws + g.has_cls;
+  const int No = g.To * g.Ho * g.Wo + g.has_cls;
+  const int64_t total = (int64_t)g.B * Ni * g.H * cpr;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+    const int c = id % cpr;
+    const int hd = (id / cpr) % g.H;
+    const int n = (id / ((int64_t)cpr * g.H)) % Ni;
+    const int b = id / ((int64_t)cpr * g.H * Ni);
+    const TD* dyb = dy + b * g.syb + hd * g.syh + c * VEC;
+    T* dxo = dx + b * g.sxb + (int64_t)n * g.sxn + hd * g.sxh + c * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
+    if (g.has_cls && n == 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = to_f32(dyb[e]);
+    } else {
+      const int i = n - g.has_cls;
+      const int ww = i % g.Ws, hh = (i / g.Ws) % g.Hs, t = i / (g.Ws * g.Hs);
+      for (int kt = 0; kt < g.kt; ++kt) {
+        const int tn = t + g.pt - kt;
+        if (tn < 0 || tn % g.st) continue;
+        const int to = tn / g.st;
+        if (to >= g.To) continue;
+        for (int kh = 0; kh < g.kh; ++kh) {
+          const int hn = hh + g.ph - kh;
+          if (hn < 0 || hn % g.sh) continue;
+          const int ho = hn / g.sh;
+          if (ho >= g.Ho) continue;
+          for (int kw = 0; kw < g.kw; ++kw) {
+            const int wn = ww + g.pw - kw;
+            if (wn < 0 || wn % g.sw) continue;
+            const int wo = wn / g.sw;
+            if (wo >= g.Wo) continue;
+            const int no = g.has_cls + (to * g.Ho + ho) * g.Wo + wo;
+            const int tap = (kt * g.kh + kh) * g.kw + kw;
+            const TD* d = dyb + (int64_t)no * g.syn;
+            if (MAXPOOL) {
+              const uint8_t* am = argmax + ((((int64_t)b * No + no) * g.H + hd) * g.C + c * VEC);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e)
+                if (am[e] == tap) acc[e] += to_f32(d[e]);
+            } else {
+              const float* wk = wlds + tap * g.C + c * VEC;
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) acc[e] += to_f32(d[e]) * wk[e];
+            }
+          }
+        }
+      }
+    }
+    V out;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out[e] = from_f32<T>(acc[e]);
+    *reinterpret_cast<V*>(dxo) = out;
+  }
+}
+
+// ---------------------------------------------------------------- depthwise weight gradient
+// dw[c][tap] += sum over (b, head, o) dy[o][c] * x[in(o, tap)][c].  4 channels per thread,
+// per-thread register accumulators over a grid-stride token loop, LDS fold, one atomic per block.
+template <typename T, typename TD>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const TD* __restrict__ dy, const T* __restrict__ x,
+                                                                float* __restrict__ dw, PoolGeom g) {
+  constexpr int CV = 4;
+  constexpr int MAXT = 27;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [taps][C]
+  const int taps = g.kt * g.kh * g.kw;
+  const int cpr = g.C / CV;
+  const int slots = blockDim.x / cpr;
+  const int c = threadIdx.x % cpr, slot = threadIdx.x / cpr;
+  for (int i = threadIdx.x; i < taps * g.C; i += blockDim.x) red[i] = 0.0f;
+  __syncthreads();
+  float acc[MAXT][CV];
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k)
+#pragma unroll
+    for (int e = 0; e < CV; ++e) acc[k][e] = 0.0f;
+  const int Ngrid = g.To * g.Ho * g.Wo;
+  const int64_t total = (int64_t)g.B * g.H * Ngrid;
+  if (slot < slots) {
+    for (int64_t id = (int64_t)blockIdx.x * slots + slot; id < total; id += (int64_t)gridDim.x * slots) {
+      const int o = id % Ngrid;
+      const int hd = (id / Ngrid) % g.H;
+      const int b = id / ((int64_t)Ngrid * g.H);
+      const int wo = o % g.Wo, ho = (o / g.Wo) % g.Ho, to = o / (g.Wo * g.Ho);
+      const TD* d = dy + b * g.syb + (int64_t)(o + g.has_cls) * g.syn + hd * g.syh + c * CV;
+      float dv[CV];
+#pragma unroll
+      for (int e = 0; e < CV; ++e) dv[e] = to_f32(d[e]);
+      const T* xb = x + b * g.sxb + hd * g.sxh + c * CV;
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const int t = to * g.st - g.pt + kt;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int hh = ho * g.sh - g.ph + kh;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int ww = wo * g.sw - g.pw + kw;
+            if (kt < g.kt && kh < g.kh && kw < g.kw && t >= 0 && t < g.T && hh >= 0 && hh < g.Hs && ww >= 0 &&
+                ww < g.Ws) {
+              const T* xi = xb + (int64_t)(g.has_cls + (t * g.Hs + hh) * g.Ws + ww) * g.sxn;
+#pragma unroll
+              for (int e = 0; e < CV; ++e) acc[(kt * 3 + kh) * 3 + kw][e] += dv[e] * to_f32(xi[e]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          if (kt < g.kt && kh < g.kh && kw < g.kw) {
+            const int tap = (kt * g.kh + kh) * g.kw + kw;
+#pragma unroll
+            for (int e = 0; e < CV; ++e) atomicAdd(&red[tap * g.C + c * CV + e], acc[(kt * 3 + kh) * 3 + kw][e]);
+          }
+        }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < taps * g.C; i += blockDim.x) {
+    const int k = i / g.C, cc = i % g.C;
+    atomicAdd(dw + cc * taps + k, red[i]);
+  }
+}
+
+inline unsigned blocks_for(int64_t total, int per_block, int cap) {
+  int64_t b = (total + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+int geom_ok(const PoolGeom& g, int vec) {
+  if (g.B <= 0 || g.H <= 0 || g.C <= 0 || g.T <= 0 || g.Hs <= 0 || g.Ws <= 0) return DCC_ERR_ARG;
+  if (g.C % vec || g.C > 1024) return DCC_ERR_UNSUPPORTED;
+  if (g.kt < 1 || g.kt > 3 || g.kh < 1 || g.kh > 3 || g.kw < 1 || g.kw > 3) return DCC_ERR_UNSUPPORTED;
+  const int64_t s[] = {g.sxb, g.sxn, g.sxh, g.syb, g.syn, g.syh};
+  for (int64_t v : s)
+    if (v % vec) return DCC_ERR_UNSUPPORTED;
+  return DCC_OK;
+}
+
+PoolGeom make_geom(const int* d, const int64_t* strides) {
+  PoolGeom g;
+  g.B = d[0]; g.H = d[1]; g.C = d[2]; g.T = d[3]; g.Hs = d[4]; g.Ws = d[5];
+  g.kt = d[6]; g.kh = d[7]; g.kw = d[8]; g.st = d[9]; g.sh = d[10]; g.sw = d[11];
+  g.pt = d[12]; g.ph = d[13]; g.pw = d[14]; g.has_cls = d[15];
+  g.To = (g.T + 2 * g.pt - g.kt) / g.st + 1;
+  g.Ho = (g.Hs + 2 * g.ph - g.kh) / g.sh + 1;
+  g.Wo = (g.Ws + 2 * g.pw - g.kw) / g.sw + 1;
+  g.sxb = strides[0]; g.sxn = strides[1]; g.sxh = strides[2];
+  g.syb = strides[3]; g.syn = strides[4]; g.syh = strides[5];
+  return g;
+}
+
+}  // namespace
+
+extern "C" int dcc_im2col3d(const float* x, void* col, int B, int T, int H, int W, int Cin, int KT, int KH, int KW,
+                            int st, int sh, int sw, int pt, int ph, int pw, int Kp, int dtype, void* stream) {
+  if (!x || !col || B <= 0) return DCC_ERR_ARG;
+  const int To = (T + 2 * pt - KT) / st + 1, Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
+  if (Kp < KT * KH * KW * Cin) return DCC_ERR_ARG;
+  const int64_t ntok = (int64_t)B * To * Ho * Wo;
+  dim3 grid((unsigned)((ntok + 3) / 4));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DCC_BF16)
+    hipLaunchKernelGGL((im2col3d_kernel<bf16_t>), grid, dim3(256), 0, s, x, (bf16_t*)col, B, T, H, W, Cin, KT, KH, KW,
+                       st, sh, sw, pt, ph, pw, To, Ho, Wo, Kp);
+  else if (dtype == DCC_F32)
+    hipLaunchKernelGGL((im2col3d_kernel<float>), grid, dim3(256), 0, s, x, (float*)col, B, T, H, W, Cin, KT, KH, KW, st,
+                       sh, sw, pt, ph, pw, To, Ho, Wo, Kp);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+// dims: [B,H,C,T,Hs,Ws,kt,kh,kw,st,sh,sw,pt,ph,pw,has_cls]; strides: [sxb,sxn,sxh,syb,syn,syh]
+// mode 0 = depthwise conv (w = [C][kt*kh*kw] fp32), mode 1 = max pool (argmax uint8 [B,No,H,C] or null)
+extern "C" int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* argmax, const int* dims,
+                            const int64_t* strides, int mode, int dtype, void* stream) {
+  if (!x || !y || !dims || !strides || (mode == 0 && !w)) return DCC_ERR_ARG;
+  PoolGeom g = make_geom(dims, strides);
+  const int vec = dtype == DCC_BF16 ? 8 : 4;
+  int rc = geom_ok(g, vec);
+  if (rc) return rc;
+  const int64_t total = (int64_t)g.B * (g.To * g.Ho * g.Wo + g.has_cls) * g.H * (g.C / vec);
+  dim3 grid(blocks_for(total, 256, 8192));
+  const size_t lds = mode == 0 ? (size_t)g.kt * g.kh * g.kw * g.C * 4 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DCC_BF16) {
+    if (mode == 0) hipLaunchKernelGGL((pool_fwd_kernel<bf16_t, false>), grid, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, w, argmax, g);
+    else hipLaunchKernelGGL((pool_fwd_kernel<bf16_t, true>), grid, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, w, argmax, g);
+  } else if (dtype == DCC_F32) {
+    if (mode == 0) hipLaunchKernelGGL((pool_fwd_kernel<float, false>), grid, dim3(256), lds, s, (const float*)x, (float*)y, w, argmax, g);
+    else hipLaunchKernelGGL((pool_fwd_kernel<float, true>), grid, dim3(256), lds, s, (const float*)x, (float*)y, w, argmax, g);
+  } else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+// dy has the y-strides, dx the x-strides. grad_dtype = element type of dy (T or fp32).
+extern "C" int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const uint8_t* argmax, const int* dims,
+                                 const int64_t* strides, int mode, int dtype, int grad_dtype, void* stream) {
+  if (!dy || !dx || !dims || !strides || (mode == 0 && !w) || (mode == 1 && !argmax)) return DCC_ERR_ARG;
+  PoolGeom g = make_geom(dims, strides);
+  const int vec = dtype == DCC_BF16 ? 8 : 4;
+  int rc = geom_ok(g, vec);
+  if (rc) return rc;
+  const int64_t total = (int64_t)g.B * (g.T * g.Hs * g.Ws + g.has_cls) * g.H * (g.C / vec);
+  dim3 grid(blocks_for(total, 256, 8192));
+  const size_t lds = mode == 0 ? (size_t)g.kt * g.kh * g.kw * g.C * 4 : 0;
+  hipStream_t s = (hipStream_t)stream;
+#define PBD(T_, TD_, MP) hipLaunchKernelGGL((pool_bwd_data_kernel<T_, TD_, MP>), grid, dim3(256), lds, s, (const TD_*)dy, (T_*)dx, w, argmax, g)
+  if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) { if (mode == 0) PBD(bf16_t, bf16_t, false); else PBD(bf16_t, bf16_t, true); }
+  else if (dtype == DCC_BF16 && grad_dtype == DCC_F32) { if (mode == 0) PBD(bf16_t, float, false); else PBD(bf16_t, float, true); }
+  else if (dtype == DCC_F32 && grad_dtype == DCC_F32) { if (mode == 0) PBD(float, float, false); else PBD(float, float, true); }
+  else return DCC_ERR_UNSUPPORTED;
+#undef PBD
+  return dcc_check_launch();
+}
+
+// dw [C][taps] fp32 is ACCUMULATED into.
+extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, const int* dims, const int64_t* strides,
+                                     int dtype, int grad_dtype, void* stream) {
+  if (!dy || !x || !dw || !dims || !strides) return DCC_ERR_ARG;
+  PoolGeom g = make_geom(dims, strides);
+  int rc = geom_ok(g, 4);
+  if (rc) return rc;
+  if (g.C / 4 > 256) return DCC_ERR_UNSUPPORTED;
+  const int slots = 256 / (g.C / 4);
+  const int64_t total = (int64_t)g.B * g.H * g.To * g.Ho * g.Wo;
+  dim3 grid(blocks_for(total, slots * 8, 1024));
+  const size_t lds = (size_t)g.kt * g.kh * g.kw * g.C * 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DCC_BF16 && grad_dtype == DCC_BF16)
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, dw, g);
+  else if (dtype == DCC_BF16 && grad_dtype == DCC_F32)
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, float>), grid, dim3(256), lds, s, (const float*)dy, (const bf16_t*)x, dw, g);
+  else if (dtype == DCC_F32 && grad_dtype == DCC_F32)
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<float, float>), grid, dim3(256), lds, s, (const float*)dy, (const float*)x, dw, g);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}

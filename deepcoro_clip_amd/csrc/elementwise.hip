@@ -1,0 +1,414 @@
+// Streaming (HBM-bound) helpers: casts, axpby, column sums (bias gradients), class-token rows,
+// token mean pooling, BERT embedding gather/scatter, 3-D RoPE rotation, learned-query softmax
+// pooling of the video aggregator, nan_to_num, dropout.
+#include "common.h"
+
+namespace {
+
+inline unsigned gs_blocks(int64_t n, int per_thread = 1) {
+  int64_t b = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = from_f32<TD>(to_f32(s[i]));
+}
+
+// strided 2-D cast/copy: d[r*ldd + c] = s[r*lds + c]
+template <typename TS, typename TD>
+__global__ void cast2d_kernel(const TS* __restrict__ s, int64_t lds_, TD* __restrict__ d, int64_t ldd, int64_t rows,
+                              int cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int c = i % cols;
+    d[r * ldd + c] = from_f32<TD>(to_f32(s[r * lds_ + c]));
+  }
+}
+
+template <typename T>
+__global__ void axpby_kernel(T* __restrict__ out, float a, const T* __restrict__ x, float b, const T* __restrict__ y,
+                             int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = a * to_f32(x[i]);
+    if (y) v += b * to_f32(y[i]);
+    out[i] = from_f32<T>(v);
+  }
+}
+
+// out = dy * gelu'(pre)
+template <typename T>
+__global__ void dgelu_mul_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = from_f32<T>(to_f32(dy[i]) * dgelu_f(to_f32(pre[i])));
+}
+
+// out[n] += sum_m x[m*ldx + n]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ out,
+                                                     int64_t M, int N) {
+  extern __shared__ float red[];
+  for (int i = threadIdx.x; i < N; i += blockDim.x) red[i] = 0.0f;
+  __syncthreads();
+  const int cpr = (N + 3) / 4;
+  const int lanes = cpr < 256 ? cpr : 256;
+  const int rpb = 256 / lanes;
+  const int r_in = threadIdx.x / lanes, c0 = threadIdx.x % lanes;
+  if (r_in < rpb) {
+    for (int cc = c0; cc < cpr; cc += lanes) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int64_t r = (int64_t)blockIdx.x * rpb + r_in; r < M; r += (int64_t)gridDim.x * rpb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cc * 4 + e < N) acc[e] += to_f32(x[r * ldx + cc * 4 + e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (cc * 4 + e < N) atomicAdd(&red[cc * 4 + e], acc[e]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += blockDim.x) atomicAdd(out + i, red[i]);
+}
+
+template <typename T>
+__global__ void broadcast_row_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t ld, int64_t rows,
+                                     int C) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[(i / C) * ld + (i % C)] = from_f32<T>(src[i % C]);
+}
+
+// y[b][d] = mean_n x[b][n][d]
+template <typename T>
+__global__ void token_mean_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int N, int D) {
+  const int64_t total = (int64_t)B * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = i / D, d = i % D;
+    float acc = 0.0f;
+    for (int n = 0; n < N; ++n) acc += to_f32(x[((int64_t)b * N + n) * D + d]);
+    y[i] = from_f32<T>(acc / N);
+  }
+}
+template <typename T>
+__global__ void token_mean_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int N, int D) {
+  const int64_t total = (int64_t)B * N * D;
+  const float inv = 1.0f / N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = i % D;
+    const int64_t b = i / ((int64_t)N * D);
+    dx[i] = from_f32<T>(to_f32(dy[b * D + d]) * inv);
+  }
+}
+
+// BERT embeddings: out[b*S+s] = word[ids] + pos[s] + type[0]   (fp32 tables -> T)
+template <typename T>
+__global__ void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                 const float* __restrict__ pos, const float* __restrict__ type, T* __restrict__ out,
+                                 int64_t rows, int S, int D, int vocab) {
+  const int64_t total = rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D;
+    const int d = i % D;
+    int64_t id = ids[r];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    out[i] = from_f32<T>(word[id * D + d] + pos[(r % S) * D + d] + type[d]);
+  }
+}
+template <typename T>
+__global__ void embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dy, float* __restrict__ dword,
+                                 float* __restrict__ dpos, float* __restrict__ dtype_, int64_t rows, int S, int D,
+                                 int vocab) {
+  const int64_t total = rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D;
+    const int d = i % D;
+    int64_t id = ids[r];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    const float g = to_f32(dy[i]);
+    if (dword) atomicAdd(dword + id * D + d, g);
+    if (dpos) atomicAdd(dpos + (r % S) * D + d, g);
+    if (dtype_) atomicAdd(dtype_ + d, g);
+  }
+}
+
+// interleaved-pair rotation: y[2i] = x[2i] c[2i] - sgn x[2i+1] s[2i];  y[2i+1] = x[2i+1] c[2i+1] + sgn x[2i] s[2i+1]
+// x: [B, N, H, D] view (strides), tables [N, D] fp32. sgn = +1 forward, -1 backward (transpose of the rotation).
+template <typename T>
+__global__ void rope_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ cs,
+                            const float* __restrict__ sn, int B, int N, int H, int D, int64_t sb, int64_t sn_, int64_t sh,
+                            int64_t yb, int64_t yn, int64_t yh, float sgn) {
+  const int half = D / 2;
+  const int64_t total = (int64_t)B * N * H * half;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = i % half;
+    const int hd = (i / half) % H;
+    const int n = (i / ((int64_t)half * H)) % N;
+    const int b = i / ((int64_t)half * H * N);
+    const T* xp = x + b * sb + (int64_t)n * sn_ + hd * sh + 2 * p;
+    T* yp = y + b * yb + (int64_t)n * yn + hd * yh + 2 * p;
+    const float x0 = to_f32(xp[0]), x1 = to_f32(xp[1]);
+    const float c0 = cs[(int64_t)n * D + 2 * p], c1 = cs[(int64_t)n * D + 2 * p + 1];
+    const float s0 = sn[(int64_t)n * D + 2 * p], s1 = sn[(int64_t)n * D + 2 * p + 1];
+    float y0, y1;
+    if (sgn > 0) { y0 = x0 * c0 - x1 * s0; y1 = x1 * c1 + x0 * s1; }
+    else { y0 = x0 * c0 + x1 * s1; y1 = x1 * c1 - x0 * s0; }
+    yp[0] = from_f32<T>(y0);
+    yp[1] = from_f32<T>(y1);
+  }
+}
+
+// learned-query softmax pooling over N tokens (EnhancedVideoAggregator tail): one block per batch row.
+// scores[n] = <q, x[n]>, w = softmax(scores), out = sum_n w[n] x[n]
+__global__ __launch_bounds__(256) void qpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ q,
+                                                        float* __restrict__ out, float* __restrict__ wout, int N,
+                                                        int D) {
+  extern __shared__ float sm[];  // scores[N]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xb = x + (int64_t)b * N * D;
+  for (int n = wave; n < N; n += 4) {
+    float acc = 0.0f;
+    for (int d = lane; d < D; d += 64) acc += q[d] * xb[(int64_t)n * D + d];
+    acc = wave_sum(acc);
+    if (lane == 0) sm[n] = acc;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int n = 0; n < N; ++n) mx = fmaxf(mx, sm[n]);
+  float den = 0.0f;
+  for (int n = 0; n < N; ++n) den += __expf(sm[n] - mx);
+  __syncthreads();
+  for (int n = tid; n < N; n += 256) {
+    const float w = __expf(sm[n] - mx) / den;
+    sm[n] = w;
+    wout[(int64_t)b * N + n] = w;
+  }
+  __syncthreads();
+  for (int d = tid; d < D; d += 256) {
+    float acc = 0.0f;
+    for (int n = 0; n < N; ++n) acc += sm[n] * xb[(int64_t)n * D + d];
+    out[(int64_t)b * D + d] = acc;
+  }
+}
+// dx[n] = w[n] dout + ds[n] q;  ds = w (dw - sum w dw), dw[n] = <dout, x[n]>;  dq += sum_n ds[n] x[n]
+__global__ __launch_bounds__(256) void qpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ q,
+                                                        const float* __restrict__ w, const float* __restrict__ dout,
+                                                        float* __restrict__ dx, float* __restrict__ dq, int N, int D) {
+  extern __shared__ float sm[];  // ds[N]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xb = x + (int64_t)b * N * D;
+  const float* wb = w + (int64_t)b * N;
+  const float* db = dout + (int64_t)b * D;
+  for (int n = wave; n < N; n += 4) {
+    float acc = 0.0f;
+    for (int d = lane; d < D; d += 64) acc += db[d] * xb[(int64_t)n * D + d];
+    acc = wave_sum(acc);
+    if (lane == 0) sm[n] = acc;
+  }
+  __syncthreads();
+  float dot = 0.0f;
+  for (int n = 0; n < N; ++n) dot += wb[n] * sm[n];
+  __syncthreads();
+  for (int n = tid; n < N; n += 256) sm[n] = wb[n] * (sm[n] - dot);
+  __syncthreads();
+  for (int d = tid; d < D; d += 256) {
+    float dqa = 0.0f;
+    for (int n = 0; n < N; ++n) {
+      dx[((int64_t)b * N + n) * D + d] = wb[n] * db[d] + sm[n] * q[d];
+      dqa += sm[n] * xb[(int64_t)n * D + d];
+    }
+    atomicAdd(dq + d, dqa);
+  }
+}
+
+template <typename T>
+__global__ void nan_to_num_kernel(T* __restrict__ x, int64_t n, float nanv, float posv, float negv,
+                                  int* __restrict__ count) {
+  int local = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = to_f32(x[i]);
+    if (v != v) { x[i] = from_f32<T>(nanv); ++local; }
+    else if (v == INFINITY) { x[i] = from_f32<T>(posv); ++local; }
+    else if (v == -INFINITY) { x[i] = from_f32<T>(negv); ++local; }
+  }
+  if (count && local) atomicAdd(count, local);
+}
+
+__device__ __forceinline__ uint32_t hash32(uint64_t k) {  // splitmix64 finaliser
+  k += 0x9e3779b97f4a7c15ULL;
+  k = (k ^ (k >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  k = (k ^ (k >> 27)) * 0x94d049bb133111ebULL;
+  k ^= k >> 31;
+  return (uint32_t)(k >> 32);
+}
+// y = x * keep / (1-p); keep regenerated from (seed, index) so no mask is stored.
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, uint64_t seed) {
+  const float scale = 1.0f / (1.0f - p);
+  const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool keep = hash32(seed * 0x100000001b3ULL + (uint64_t)i) >= thr;
+    y[i] = keep ? from_f32<T>(to_f32(x[i]) * scale) : from_f32<T>(0.0f);
+  }
+}
+
+// x[i] *= *coef  (device-side coefficient, e.g. gradient clipping)
+__global__ void scale_by_dev_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ coef) {
+  const float c = *coef;
+  if (c == 1.0f) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= c;
+}
+
+}  // namespace
+
+#define ST (hipStream_t) stream
+
+extern "C" int dcc_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream) {
+  if (!src || !dst || n <= 0) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(n, 4));
+  if (src_dtype == DCC_F32 && dst_dtype == DCC_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, dim3(256), 0, ST, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == DCC_BF16 && dst_dtype == DCC_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, dim3(256), 0, ST, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == DCC_F32 && dst_dtype == DCC_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, dim3(256), 0, ST, (const float*)src, (float*)dst, n);
+  else if (src_dtype == DCC_BF16 && dst_dtype == DCC_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)src, (bf16_t*)dst, n);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_cast2d(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int cols, int src_dtype,
+                          int dst_dtype, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(rows * cols, 4));
+  if (src_dtype == DCC_F32 && dst_dtype == DCC_BF16) hipLaunchKernelGGL((cast2d_kernel<float, bf16_t>), g, dim3(256), 0, ST, (const float*)src, lds_, (bf16_t*)dst, ldd, rows, cols);
+  else if (src_dtype == DCC_BF16 && dst_dtype == DCC_F32) hipLaunchKernelGGL((cast2d_kernel<bf16_t, float>), g, dim3(256), 0, ST, (const bf16_t*)src, lds_, (float*)dst, ldd, rows, cols);
+  else if (src_dtype == DCC_F32 && dst_dtype == DCC_F32) hipLaunchKernelGGL((cast2d_kernel<float, float>), g, dim3(256), 0, ST, (const float*)src, lds_, (float*)dst, ldd, rows, cols);
+  else if (src_dtype == DCC_BF16 && dst_dtype == DCC_BF16) hipLaunchKernelGGL((cast2d_kernel<bf16_t, bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)src, lds_, (bf16_t*)dst, ldd, rows, cols);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_axpby(void* out, float a, const void* x, float b, const void* y, int64_t n, int dtype, void* stream) {
+  if (!out || !x || n <= 0) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(n, 4));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((axpby_kernel<bf16_t>), g, dim3(256), 0, ST, (bf16_t*)out, a, (const bf16_t*)x, b, (const bf16_t*)y, n);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((axpby_kernel<float>), g, dim3(256), 0, ST, (float*)out, a, (const float*)x, b, (const float*)y, n);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_dgelu_mul(const void* dy, const void* pre, void* out, int64_t n, int dtype, void* stream) {
+  if (!dy || !pre || !out || n <= 0) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(n, 4));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((dgelu_mul_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)dy, (const bf16_t*)pre, (bf16_t*)out, n);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((dgelu_mul_kernel<float>), g, dim3(256), 0, ST, (const float*)dy, (const float*)pre, (float*)out, n);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_colsum(const void* x, int64_t ldx, float* out, int64_t M, int N, int dtype, void* stream) {
+  if (!x || !out || M <= 0 || N <= 0 || N > 8192) return DCC_ERR_ARG;
+  int64_t blocks = (M + 63) / 64;
+  if (blocks > 1024) blocks = 1024;
+  dim3 g((unsigned)blocks);
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), g, dim3(256), N * 4, ST, (const bf16_t*)x, ldx, out, M, N);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((colsum_kernel<float>), g, dim3(256), N * 4, ST, (const float*)x, ldx, out, M, N);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_broadcast_row(const float* src, void* dst, int64_t ld, int64_t rows, int C, int dtype, void* stream) {
+  if (!src || !dst || rows <= 0 || C <= 0) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(rows * C));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((broadcast_row_kernel<bf16_t>), g, dim3(256), 0, ST, src, (bf16_t*)dst, ld, rows, C);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((broadcast_row_kernel<float>), g, dim3(256), 0, ST, src, (float*)dst, ld, rows, C);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_token_mean(const void* in, void* out, int B, int N, int D, int backward, int dtype, void* stream) {
+  if (!in || !out || B <= 0 || N <= 0 || D <= 0) return DCC_ERR_ARG;
+  const int64_t total = backward ? (int64_t)B * N * D : (int64_t)B * D;
+  dim3 g(gs_blocks(total));
+  if (dtype == DCC_BF16) {
+    if (backward) hipLaunchKernelGGL((token_mean_bwd_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, B, N, D);
+    else hipLaunchKernelGGL((token_mean_fwd_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, B, N, D);
+  } else if (dtype == DCC_F32) {
+    if (backward) hipLaunchKernelGGL((token_mean_bwd_kernel<float>), g, dim3(256), 0, ST, (const float*)in, (float*)out, B, N, D);
+    else hipLaunchKernelGGL((token_mean_fwd_kernel<float>), g, dim3(256), 0, ST, (const float*)in, (float*)out, B, N, D);
+  } else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type, void* out,
+                             int64_t rows, int S, int D, int vocab, int dtype, void* stream) {
+  if (!ids || !word || !pos || !type || !out || rows <= 0) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(rows * D));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((embed_fwd_kernel<bf16_t>), g, dim3(256), 0, ST, ids, word, pos, type, (bf16_t*)out, rows, S, D, vocab);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((embed_fwd_kernel<float>), g, dim3(256), 0, ST, ids, word, pos, type, (float*)out, rows, S, D, vocab);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_embed_bwd(const int64_t* ids, const void* dy, float* dword, float* dpos, float* dtype_, int64_t rows,
+                             int S, int D, int vocab, int dtype, void* stream) {
+  if (!ids || !dy || rows <= 0) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(rows * D));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), g, dim3(256), 0, ST, ids, (const bf16_t*)dy, dword, dpos, dtype_, rows, S, D, vocab);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((embed_bwd_kernel<float>), g, dim3(256), 0, ST, ids, (const float*)dy, dword, dpos, dtype_, rows, S, D, vocab);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+// strides: [x_b, x_n, x_h, y_b, y_n, y_h]
+extern "C" int dcc_rope(const void* x, void* y, const float* cos_t, const float* sin_t, int B, int N, int H, int D,
+                        const int64_t* strides, int backward, int dtype, void* stream) {
+  if (!x || !y || !cos_t || !sin_t || !strides || (D & 1)) return DCC_ERR_ARG;
+  dim3 g(gs_blocks((int64_t)B * N * H * (D / 2)));
+  const float sgn = backward ? -1.0f : 1.0f;
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((rope_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, cos_t, sin_t, B, N, H, D, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5], sgn);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((rope_kernel<float>), g, dim3(256), 0, ST, (const float*)x, (float*)y, cos_t, sin_t, B, N, H, D, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5], sgn);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_qpool_fwd(const float* x, const float* q, float* out, float* w, int B, int N, int D, void* stream) {
+  if (!x || !q || !out || !w || B <= 0 || N <= 0 || N > 8192) return DCC_ERR_ARG;
+  hipLaunchKernelGGL(qpool_fwd_kernel, dim3(B), dim3(256), N * 4, ST, x, q, out, w, N, D);
+  return dcc_check_launch();
+}
+extern "C" int dcc_qpool_bwd(const float* x, const float* q, const float* w, const float* dout, float* dx, float* dq,
+                             int B, int N, int D, void* stream) {
+  if (!x || !q || !w || !dout || !dx || !dq || B <= 0 || N <= 0 || N > 8192) return DCC_ERR_ARG;
+  hipLaunchKernelGGL(qpool_bwd_kernel, dim3(B), dim3(256), N * 4, ST, x, q, w, dout, dx, dq, N, D);
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_nan_to_num(void* x, int64_t n, float nanv, float posv, float negv, int* count, int dtype, void* stream) {
+  if (!x || n <= 0) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(n, 4));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((nan_to_num_kernel<bf16_t>), g, dim3(256), 0, ST, (bf16_t*)x, n, nanv, posv, negv, count);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((nan_to_num_kernel<float>), g, dim3(256), 0, ST, (float*)x, n, nanv, posv, negv, count);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+// The same (seed) regenerates the same keep-mask: call with x = dy for the backward.
+extern "C" int dcc_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+  if (!x || !y || n <= 0 || p < 0.0f || p >= 1.0f) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(n, 4));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, n, p, seed);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((dropout_kernel<float>), g, dim3(256), 0, ST, (const float*)x, (float*)y, n, p, seed);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_scale_by_dev(float* x, int64_t n, const float* coef, void* stream) {
+  if (!x || !coef || n <= 0) return DCC_ERR_ARG;
+  hipLaunchKernelGGL(scale_by_dev_kernel, dim3(gs_blocks(n, 4)), dim3(256), 0, ST, x, n, coef);
+  return dcc_check_launch();
+}

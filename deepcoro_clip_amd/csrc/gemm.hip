@@ -32,6 +32,7 @@ struct GemmParams {
   int batch, splitk;
   float alpha;
   int flags;
+  int unaligned;  // 1: operands break the 16-byte chunk rules -> element-wise guarded loads
 };
 
 namespace {
@@ -53,7 +54,7 @@ __device__ __forceinline__ int swz_km(int krow) { return ((krow & 3) << 2) | ((k
 // global -> registers. `row0` is the tile origin in the non-reduction dimension, `dim` its extent.
 template <typename T, bool KM>
 __device__ __forceinline__ void g2r(vec16_t<T>* regs, const T* base, int64_t ld, int row0, int dim, int k0, int kend,
-                                    int tid) {
+                                    int tid, bool unaligned) {
   using OT = OpTile<T, KM>;
   using V = typename Vec16<T>::type;
 #pragma unroll
@@ -65,10 +66,26 @@ __device__ __forceinline__ void g2r(vec16_t<T>* regs, const T* base, int64_t ld,
     for (int e = 0; e < OT::CH; ++e) v[e] = (T)0.0f;
     if (!KM) {
       const int gr = row0 + r, gk = k0 + c * OT::CH;
-      if (gr < dim && gk < kend) v = *reinterpret_cast<const V*>(base + (int64_t)gr * ld + gk);
+      if (gr < dim && gk < kend) {
+        const T* src = base + (int64_t)gr * ld + gk;
+        if (!unaligned) v = *reinterpret_cast<const V*>(src);
+        else {
+#pragma unroll
+          for (int e = 0; e < OT::CH; ++e)
+            if (gk + e < kend) v[e] = src[e];
+        }
+      }
     } else {
       const int gk = k0 + r, gc = row0 + c * OT::CH;
-      if (gk < kend && gc < dim) v = *reinterpret_cast<const V*>(base + (int64_t)gk * ld + gc);
+      if (gk < kend && gc < dim) {
+        const T* src = base + (int64_t)gk * ld + gc;
+        if (!unaligned) v = *reinterpret_cast<const V*>(src);
+        else {
+#pragma unroll
+          for (int e = 0; e < OT::CH; ++e)
+            if (gc + e < dim) v[e] = src[e];
+        }
+      }
     }
     regs[i] = v;
   }
@@ -159,8 +176,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
 
   typename Vec16<T>::type ra[OA::NCH], rb[OB::NCH];
   if (nk > 0) {
-    g2r<T, A_KM>(ra, A, p.lda, m0, p.M, ks0 * BK, kend, tid);
-    g2r<T, B_KM>(rb, B, p.ldb, n0, p.N, ks0 * BK, kend, tid);
+    g2r<T, A_KM>(ra, A, p.lda, m0, p.M, ks0 * BK, kend, tid, p.unaligned);
+    g2r<T, B_KM>(rb, B, p.ldb, n0, p.N, ks0 * BK, kend, tid, p.unaligned);
     r2s<T, A_KM>(ra, smem, tid);
     r2s<T, B_KM>(rb, smem + OA::BYTES, tid);
   }
@@ -173,8 +190,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     char* nxtA = smem + (cur ^ 1) * STAGE;
     char* nxtB = nxtA + OA::BYTES;
     if (kt + 1 < nk) {
-      g2r<T, A_KM>(ra, A, p.lda, m0, p.M, (ks0 + kt + 1) * BK, kend, tid);
-      g2r<T, B_KM>(rb, B, p.ldb, n0, p.N, (ks0 + kt + 1) * BK, kend, tid);
+      g2r<T, A_KM>(ra, A, p.lda, m0, p.M, (ks0 + kt + 1) * BK, kend, tid, p.unaligned);
+      g2r<T, B_KM>(rb, B, p.ldb, n0, p.N, (ks0 + kt + 1) * BK, kend, tid, p.unaligned);
     }
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
@@ -247,18 +264,20 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0) return DCC_ERR_ARG;
   if (!A || !B || !C) return DCC_ERR_ARG;
   const int ch = in_dtype == DCC_BF16 ? 8 : 4;
-  // 16-byte chunk loads: contiguous extents and pitches must be chunk multiples, bases 16-B aligned
-  if ((lda % ch) || (ldb % ch)) return DCC_ERR_UNSUPPORTED;
-  if ((!a_km && (K % ch)) || (a_km && (M % ch))) return DCC_ERR_UNSUPPORTED;
-  if ((!b_km && (K % ch)) || (b_km && (N % ch))) return DCC_ERR_UNSUPPORTED;
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return DCC_ERR_UNSUPPORTED;
-  if ((sA % ch) || (sB % ch)) return DCC_ERR_UNSUPPORTED;
+  // 16-byte chunk loads need chunk-multiple pitches/extents and 16-byte aligned bases; otherwise fall back to
+  // element-wise guarded loads (tiny loss-side GEMMs with odd batch sizes land here)
+  int unaligned = 0;
+  if ((lda % ch) || (ldb % ch)) unaligned = 1;
+  if ((!a_km && (K % ch)) || (a_km && (M % ch))) unaligned = 1;
+  if ((!b_km && (K % ch)) || (b_km && (N % ch))) unaligned = 1;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) unaligned = 1;
+  if ((sA % ch) || (sB % ch)) unaligned = 1;
   if ((splitk > 1 || (flags & GEMM_ACCUM)) && out_dtype != DCC_F32) return DCC_ERR_ARG;
   if ((flags & GEMM_BIAS) && !bias) return DCC_ERR_ARG;
   if ((flags & GEMM_RESID) && !R) return DCC_ERR_ARG;
   if ((flags & (GEMM_SAVE_PRE | GEMM_DGELU)) && !aux) return DCC_ERR_ARG;
   if (splitk > 1 && (flags & ~(GEMM_BIAS | GEMM_ACCUM))) return DCC_ERR_ARG;  // non-linear epilogues need the full sum
-  GemmParams p{A, B, C, bias, R, aux, lda, ldb, ldc, ldr, ldaux, sA, sB, sC, M, N, K, batch, splitk, alpha, flags};
+  GemmParams p{A, B, C, bias, R, aux, lda, ldb, ldc, ldr, ldaux, sA, sB, sC, M, N, K, batch, splitk, alpha, flags, unaligned};
   const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (tiles > 0x7fffffffLL || (int64_t)batch * splitk > 65535) return DCC_ERR_ARG;
   dim3 grid((unsigned)tiles, 1, (unsigned)(batch * splitk));

@@ -1,0 +1,189 @@
+"""Data-parallel communication for one process per GPU over RCCL/xGMI (reference: utils/ddp.py:11-136 and the two
+`DistributedDataParallel` wrappers of projects/contrastive_pretraining_project.py:107-114).
+
+`HipDDP` keeps the reference's wrapper contract (`.module`, `forward` passthrough, `device_ids=` kwarg) but is built
+for the MI355X node rather than translating torch's reducer:
+  * gradients live in ONE flat fp32 arena per wrapper; `param.grad` are views into it, so autograd accumulates in
+    place and buckets need no copy-in / copy-out;
+  * buckets are large (default 64 MiB): xGMI is point-to-point (7 links x ~153 GB/s), ring/direct collectives are
+    per-link bound, so few large messages beat DDP's 25 MiB NVSwitch-era default;
+  * a bucket's all-reduce (AVG) is launched from a post-accumulate-grad hook as soon as its last gradient is
+    written — RCCL runs it on its own stream, overlapped with the rest of backward; `finish()` joins them.
+The same code path runs on gloo/CPU for the world_size-2 tests (SUM + divide, since gloo has no AVG).
+"""
+from __future__ import annotations
+
+import os
+from typing import Any
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as MP
+import torch.utils.data.distributed as DS
+
+
+class HipDDP(torch.nn.Module):
+    def __init__(self, module: torch.nn.Module, device_ids=None, bucket_mb: float = 64.0, **_ignored):
+        super().__init__()
+        self.module = module
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._params = [p for p in module.parameters()]
+        self._bucket_bytes = int(bucket_mb * (1 << 20))
+        self._handles: list = []
+        self._arena: torch.Tensor | None = None
+        self._buckets: list[tuple[int, int]] = []
+        self._pending: list[int] = []
+        self._bucket_of: dict[int, int] = {}
+        self._hooks_installed = False
+        if self.world > 1:
+            self._broadcast_parameters()
+        self._build_arena()
+
+    # ---------------------------------------------------------------------------------------------- setup
+    def _broadcast_parameters(self):
+        with torch.no_grad():
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                dist.broadcast(t.data, src=0)
+
+    def _build_arena(self):
+        """Flat gradient arena in REVERSE parameter order (roughly the order backward produces gradients)."""
+        ps = [p for p in reversed(self._params)]
+        if not ps:
+            return
+        dev, total = ps[0].device, 0
+        offs = []
+        for p in ps:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4  # keep every view 16-byte aligned
+        self._arena = torch.zeros(total, device=dev, dtype=torch.float32)
+        self._views = {}
+        start, b = 0, 0
+        for p, o in zip(ps, offs):
+            self._views[id(p)] = self._arena[o:o + p.numel()].view(p.shape)
+            if (o + p.numel() - start) * 4 > self._bucket_bytes and o > start:
+                self._buckets.append((start, o))
+                start, b = o, b + 1
+            self._bucket_of[id(p)] = b
+        self._buckets.append((start, total))
+        self._order = ps
+
+    def attach_grads(self):
+        """Zero the arena and (re)attach `param.grad` views; call instead of optimizer.zero_grad(set_to_none=True)."""
+        if self._arena is None:
+            return
+        self._arena.zero_()
+        for p in self._order:
+            p.grad = self._views[id(p)] if p.requires_grad else None
+        self._pending = [0] * len(self._buckets)
+        for p in self._order:
+            if p.requires_grad:
+                self._pending[self._bucket_of[id(p)]] += 1
+        self._handles = []
+        if self.world > 1 and not self._hooks_installed:
+            for p in self._order:
+                p.register_post_accumulate_grad_hook(self._make_hook(p))
+            self._hooks_installed = True
+
+    def _make_hook(self, p):
+        def hook(param):
+            b = self._bucket_of[id(p)]
+            if b >= len(self._pending):
+                return
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+
+        return hook
+
+    def _launch(self, b: int):
+        lo, hi = self._buckets[b]
+        buf = self._arena[lo:hi]
+        if dist.get_backend() == "nccl":
+            self._handles.append((dist.all_reduce(buf, op=dist.ReduceOp.AVG, async_op=True), None))
+        else:
+            self._handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), buf))
+
+    def finish(self):
+        """Join the bucket all-reduces (also launches buckets whose hooks never fired, e.g. unused parameters)."""
+        if self.world <= 1 or self._arena is None:
+            return
+        for b, n in enumerate(self._pending):
+            if n > 0:
+                self._pending[b] = 0
+                self._launch(b)
+        for h, buf in self._handles:
+            h.wait()
+            if buf is not None:
+                buf.div_(self.world)
+        self._handles = []
+
+    # ------------------------------------------------------------------------------------------- nn.Module
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def state_dict(self, *args, **kwargs):
+        return self.module.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        return self.module.load_state_dict(*args, **kwargs)
+
+
+class DistributedUtils:
+    """utils/ddp.py:11-136 with RCCL ('nccl' on ROCm) on GPUs and gloo on CPU."""
+
+    MP = MP
+    DS = DS
+    DDP = HipDDP
+    dist = dist
+
+    @staticmethod
+    def is_initialized():
+        return dist.is_initialized()
+
+    @staticmethod
+    def ddp_setup(gpu_id: int, world_size: int):
+        local_rank = int(os.environ.get("LOCAL_RANK", gpu_id if isinstance(gpu_id, int) else 0))
+        rank = int(os.environ.get("RANK", gpu_id if isinstance(gpu_id, int) else 0))
+        backend = "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+            backend = "nccl"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, init_method="env://", world_size=world_size, rank=rank, **kw)
+
+    @staticmethod
+    def ddp_cleanup():
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+    @staticmethod
+    def sync_process_group(world_size: int, device_ids: int):
+        if world_size > 1 and dist.is_initialized():
+            dist.barrier()
+
+    @staticmethod
+    def gather_loss(loss: list, device: int) -> float:
+        t = torch.tensor(loss, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.mean().item() / dist.get_world_size()
+
+    @staticmethod
+    def gather_object(obj: Any, world_size: int) -> list:
+        if world_size <= 1:
+            return [obj]
+        out = [None for _ in range(world_size)]
+        dist.all_gather_object(out, obj)
+        return out
+
+    @staticmethod
+    def gather_tensor(tensor: torch.Tensor, world_size: int) -> torch.Tensor:
+        if world_size <= 1:
+            return tensor
+        t = tensor.contiguous()
+        out = torch.empty((world_size * t.shape[0], *t.shape[1:]), device=t.device, dtype=t.dtype)
+        dist.all_gather_into_tensor(out, t)
+        return out

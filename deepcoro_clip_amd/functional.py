@@ -1,0 +1,518 @@
+"""Autograd glue: `torch.autograd.Function`s whose forward AND backward are HIP kernels.
+
+torch supplies the tape, device memory and views; every arithmetic step calls `kernels.py`
+(-> libdcc_hip.so).  Activations live in the compute dtype (bf16 or fp32), parameters stay fp32
+masters with cached bf16 shadows, weight/bias gradients come back in fp32.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import kernels as K
+
+# ------------------------------------------------------------------------------ weight shadows
+_WCACHE: dict = {}
+_WEPOCH = 0
+
+
+def invalidate_weight_cache() -> None:
+    """Call after parameters were updated through raw pointers (our fused optimizer)."""
+    global _WEPOCH
+    _WEPOCH += 1
+    _WCACHE.clear()
+
+
+def wcast(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 parameter -> contiguous tensor in the compute dtype (cached per parameter version)."""
+    wd = w.detach()
+    if dtype == torch.float32:
+        return wd if wd.is_contiguous() else wd.contiguous()
+    key = (wd.data_ptr(), tuple(wd.shape), dtype)
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0] == w._version:
+        return hit[1]
+    src = wd if wd.is_contiguous() else wd.contiguous()
+    t = K.cast(src, dtype)
+    _WCACHE[key] = (w._version, t)
+    return t
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _as_dtype(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    return t if t.dtype == dtype else K.cast(_c(t), dtype)
+
+
+# ------------------------------------------------------------------------------------- Linear
+class LinearFn(torch.autograd.Function):
+    """y = [gelu](x W^T + b) [+ residual]   (nn.Linear [+ nn.GELU] [+ skip add])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gelu, residual):
+        K_ = x.shape[-1]
+        N = weight.shape[0]
+        x2 = _c(x).reshape(-1, K_)
+        wc = wcast(weight, x.dtype)
+        res2 = _c(residual).reshape(-1, N) if residual is not None else None
+        pre = torch.empty((x2.shape[0], N), device=x.device, dtype=x.dtype) if gelu else None
+        y = K.gemm(x2, wc, bias=bias.detach() if bias is not None else None, gelu=gelu, save_pre=gelu, aux=pre, resid=res2)
+        ctx.save_for_backward(x2, wc, pre)
+        ctx.gelu = gelu
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wc, pre = ctx.saved_tensors
+        N = wc.shape[0]
+        dy2 = _c(dy).reshape(-1, N)
+        g = K.dgelu_mul(dy2, pre) if ctx.gelu else dy2
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = K.gemm(g, wc, b_km=True).reshape(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = K.gemm(g, x2, a_km=True, b_km=True, out_dtype=torch.float32,
+                        splitk=K.wgrad_splitk(g.shape[0], N, x2.shape[1]))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = K.colsum(g)
+        if ctx.has_res and ctx.needs_input_grad[4]:
+            dres = dy
+        return dx, dw, db, None, dres
+
+
+def linear(x, weight, bias=None, gelu: bool = False, residual=None):
+    return LinearFn.apply(x, weight, bias, gelu, residual)
+
+
+class MlpFn(torch.autograd.Function):
+    """y = W2 gelu(W1 x + b1) + b2 [+ residual]; backward fuses gelu' into the fc2 data-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual):
+        Kd = x.shape[-1]
+        x2 = _c(x).reshape(-1, Kd)
+        w1c, w2c = wcast(w1, x.dtype), wcast(w2, x.dtype)
+        Hd, N = w1.shape[0], w2.shape[0]
+        pre = torch.empty((x2.shape[0], Hd), device=x.device, dtype=x.dtype)
+        act = K.gemm(x2, w1c, bias=b1.detach(), gelu=True, save_pre=True, aux=pre)
+        res2 = _c(residual).reshape(-1, N) if residual is not None else None
+        y = K.gemm(act, w2c, bias=b2.detach(), resid=res2)
+        ctx.save_for_backward(x2, w1c, w2c, pre, act)
+        ctx.has_res = residual is not None
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1c, w2c, pre, act = ctx.saved_tensors
+        Hd, N = w1c.shape[0], w2c.shape[0]
+        dy2 = _c(dy).reshape(-1, N)
+        rows = dy2.shape[0]
+        dw2 = db2 = dw1 = db1 = dx = None
+        if ctx.needs_input_grad[3]:
+            dw2 = K.gemm(dy2, act, a_km=True, b_km=True, out_dtype=torch.float32, splitk=K.wgrad_splitk(rows, N, Hd))
+        if ctx.needs_input_grad[4]:
+            db2 = K.colsum(dy2)
+        dpre = K.gemm(dy2, w2c, b_km=True, dgelu=True, aux=pre)
+        if ctx.needs_input_grad[1]:
+            dw1 = K.gemm(dpre, x2, a_km=True, b_km=True, out_dtype=torch.float32,
+                         splitk=K.wgrad_splitk(rows, Hd, x2.shape[1]))
+        if ctx.needs_input_grad[2]:
+            db1 = K.colsum(dpre)
+        if ctx.needs_input_grad[0]:
+            dx = K.gemm(dpre, w1c, b_km=True).reshape(ctx.xshape)
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
+
+
+def mlp(x, w1, b1, w2, b2, residual=None):
+    return MlpFn.apply(x, w1, b1, w2, b2, residual)
+
+
+# ---------------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        y, mean, rstd = K.layernorm_fwd(x2, gamma.detach(), beta.detach(), eps)
+        ctx.save_for_backward(x2, mean, rstd, gamma.detach())
+        ctx.xshape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, gamma = ctx.saved_tensors
+        C = x2.shape[1]
+        dy2 = _as_dtype(_c(dy).reshape(-1, C), x2.dtype)
+        dg = torch.zeros(C, device=x2.device, dtype=torch.float32)
+        db = torch.zeros(C, device=x2.device, dtype=torch.float32)
+        dx = K.layernorm_bwd(dy2, x2, mean, rstd, gamma, dg, db)
+        return dx.reshape(ctx.xshape), dg, db, None
+
+
+def layernorm(x, gamma, beta, eps: float):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+# ---------------------------------------------------------------------------------- attention
+class AttentionFn(torch.autograd.Function):
+    """softmax(scale q k^T + kbias) v on [B, N, H, D] views (BERT self-attention, nn.MultiheadAttention core)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, kbias, scale):
+        o, lse = K.attn_fwd(q, k, v, scale=scale, kbias=kbias)
+        ctx.save_for_backward(q, k, v, o, lse, kbias)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, kbias = ctx.saved_tensors
+        do = _c(do)
+        dq, dk, dv = K.attn_bwd(q, k, v, o, do, lse, scale=ctx.scale, kbias=kbias)
+        return dq, _as_dtype(dk, q.dtype), _as_dtype(dv, q.dtype), None, None
+
+
+def attention(q, k, v, scale: float, kbias=None):
+    return AttentionFn.apply(q, k, v, kbias, scale)
+
+
+# --------------------------------------------------------------------- MViT pooled attention core
+def relpos_index(q_size: int, k_size: int) -> torch.Tensor:
+    """dist = arange(q)*q_ratio - (arange(k) + (1-k))*k_ratio, truncated (torchvision mvit._add_rel_pos)."""
+    q_ratio = max(k_size / q_size, 1.0)
+    k_ratio = max(q_size / k_size, 1.0)
+    dist = torch.arange(q_size)[:, None] * q_ratio - (torch.arange(k_size)[None, :] + (1.0 - k_size)) * k_ratio
+    return dist.long().to(torch.int32).contiguous()
+
+
+def relpos_aug_width(k_thw) -> int:
+    need = k_thw[0] + k_thw[1] + k_thw[2]
+    return 32 * ((need + 31) // 32)
+
+
+class MvitAttnCoreFn(torch.autograd.Function):
+    """qkv -> Pool(q,k,v) (dw conv3d + LayerNorm) -> [3-D RoPE] -> rel-pos tables -> flash attention (+ residual pool).
+
+    Follows torchvision MultiscaleAttention.forward as called from models/video_encoder.py:232-253 (non-RoPE) and the
+    patched forward of models/video_encoder.py:268-378 (RoPE: rotation after pooling, no residual shortcut).
+    Input qkv: [B*N, 3*H*D] (output of the qkv GEMM); output: [B*Nq, H*D].
+    """
+
+    @staticmethod
+    def forward(ctx, qkv, wq, wk, wv, gq, bq, gk, bk, gv, bv, rel_h, rel_w, rel_t, cfg):
+        B, N, H, D = cfg["B"], cfg["N"], cfg["H"], cfg["D"]
+        thw, eps = cfg["thw"], cfg["eps"]
+        dt = qkv.dtype
+        qkv5 = qkv.view(B, N, 3, H, D)
+        geo = {}
+        conv = {}
+        for name, idx, w, stride in (("q", 0, wq, cfg["stride_q"]), ("k", 1, wk, cfg["stride_kv"]), ("v", 2, wv, cfg["stride_kv"])):
+            g = K.PoolGeom(B, H, D, tuple(thw), (3, 3, 3), tuple(stride), (1, 1, 1), True)
+            geo[name] = g
+            conv[name], _ = K.pool_fwd(qkv5[:, :, idx], g, w.detach().reshape(D, 27))
+        q_thw, k_thw = geo["q"].out_thw, geo["k"].out_thw
+        Nq, Nk = geo["q"].n_out, geo["k"].n_out
+        A = relpos_aug_width(k_thw)
+        DQK = D + A
+        Qf = torch.empty((B, Nq, H, DQK), device=qkv.device, dtype=dt)
+        Kf = torch.empty((B, Nk, H, DQK), device=qkv.device, dtype=dt)
+        _, mq, rq = K.layernorm_fwd(conv["q"].view(-1, D), gq.detach(), bq.detach(), eps, out=Qf.view(-1, DQK)[:, :D])
+        _, mk, rk = K.layernorm_fwd(conv["k"].view(-1, D), gk.detach(), bk.detach(), eps, out=Kf.view(-1, DQK)[:, :D])
+        Vn, mv, rv = K.layernorm_fwd(conv["v"].view(-1, D), gv.detach(), bv.detach(), eps)
+        Vn = Vn.view(B, Nk, H, D)
+        rope = cfg.get("rope")
+        if rope is not None:
+            K.rope(Qf[..., :D], Qf[..., :D], rope["cos_q"], rope["sin_q"])
+            K.rope(Kf[..., :D], Kf[..., :D], rope["cos_k"], rope["sin_k"])
+        scale = cfg["scale"]
+        idx = cfg["idx"]
+        rel = (rel_h.detach(), rel_w.detach(), rel_t.detach())
+        dims_q = K.relpos_dims(B, H, D, A, q_thw, k_thw)
+        K.relpos_tab_fwd(Qf, rel, idx, dims_q, scale)
+        K.relpos_kaug(Kf, dims_q)
+        residual = rope is None
+        O, lse = K.attn_fwd(Qf, Kf, Vn, scale=scale, residual=residual, res_start=1)
+        ctx.save_for_backward(qkv, conv["q"], conv["k"], conv["v"], mq, rq, mk, rk, mv, rv, Qf, Kf, Vn, O, lse,
+                              wq.detach(), wk.detach(), wv.detach(), gq.detach(), gk.detach(), gv.detach(), *rel)
+        ctx.cfg, ctx.geo, ctx.A, ctx.residual = cfg, geo, A, residual
+        return O.view(B * Nq, H * D)
+
+    @staticmethod
+    def backward(ctx, dO):
+        (qkv, cq, ck, cv, mq, rq, mk, rk, mv, rv, Qf, Kf, Vn, O, lse, wq, wk, wv, gq, gk, gv, rel_h, rel_w,
+         rel_t) = ctx.saved_tensors
+        cfg, geo, A = ctx.cfg, ctx.geo, ctx.A
+        B, N, H, D = cfg["B"], cfg["N"], cfg["H"], cfg["D"]
+        dt = qkv.dtype
+        dev = qkv.device
+        Nq, Nk = geo["q"].n_out, geo["k"].n_out
+        DQK = D + A
+        scale = cfg["scale"]
+        dO4 = _c(dO).view(B, Nq, H, D)
+        dQf, dKf, dVn = K.attn_bwd(Qf, Kf, Vn, O, dO4, lse, scale=scale, residual=ctx.residual, res_start=1)
+        # queries: attention path + residual shortcut + table path, and the table gradients
+        dq = torch.empty((B, Nq, H, D), device=dev, dtype=dt)
+        f32 = dict(device=dev, dtype=torch.float32)
+        drel = (torch.zeros(rel_h.shape, **f32), torch.zeros(rel_w.shape, **f32), torch.zeros(rel_t.shape, **f32))
+        dims_q = K.relpos_dims(B, H, D, A, geo["q"].out_thw, geo["k"].out_thw)
+        K.relpos_tab_bwd(Qf, dQf, dO4 if ctx.residual else None, dq, (rel_h, rel_w, rel_t), drel, cfg["idx"], dims_q,
+                         scale)
+        dk = dKf[..., :D]  # the one-hot columns are constants
+        rope = cfg.get("rope")
+        if rope is not None:
+            K.rope(dq, dq, rope["cos_q"], rope["sin_q"], backward=True)
+            dk_d = torch.empty((B, Nk, H, D), device=dev, dtype=dKf.dtype)
+            K.rope(dk, dk_d, rope["cos_k"], rope["sin_k"], backward=True)
+            dk = dk_d
+        dqkv = torch.empty((B, N, 3, H, D), device=dev, dtype=dt)
+        grads = {}
+        for name, i, dy4, conv, mean, rstd, gam, w in (("q", 0, dq, cq, mq, rq, gq, wq), ("k", 1, dk, ck, mk, rk, gk, wk),
+                                                         ("v", 2, dVn, cv, mv, rv, gv, wv)):
+            g = geo[name]
+            rows = B * g.n_out * H
+            if dy4.is_contiguous():
+                dy2 = dy4.view(rows, D)
+            else:  # dk is a column slice of the [.., DQK] buffer: rows are strided by DQK
+                dy2 = dy4.as_strided((rows, D), (dy4.stride(2), 1), dy4.storage_offset())
+            dgam = torch.zeros(D, **f32)
+            dbet = torch.zeros(D, **f32)
+            dconv = K.layernorm_bwd(dy2, conv.view(rows, D), mean, rstd, gam, dgam, dbet)
+            dconv4 = dconv.view(B, g.n_out, H, D)
+            K.pool_bwd_data(dconv4, dqkv[:, :, i], g, w.reshape(D, 27))
+            dw = torch.zeros((D, 27), **f32)
+            K.dwconv_bwd_weight(dconv4, qkv.view(B, N, 3, H, D)[:, :, i], g, dw)
+            grads[name] = (dw.view(D, 1, 3, 3, 3), dgam, dbet)
+        return (dqkv.view(B * N, 3 * H * D), grads["q"][0], grads["k"][0], grads["v"][0], grads["q"][1], grads["q"][2],
+                grads["k"][1], grads["k"][2], grads["v"][1], grads["v"][2], drel[0], drel[1], drel[2], None)
+
+
+def mvit_attention_core(qkv, wq, wk, wv, gq, bq, gk, bk, gv, bv, rel_h, rel_w, rel_t, cfg):
+    return MvitAttnCoreFn.apply(qkv, wq, wk, wv, gq, bq, gk, bk, gv, bv, rel_h, rel_w, rel_t, cfg)
+
+
+# ----------------------------------------------------------------------------- skip-path max pool
+class PoolSkipFn(torch.autograd.Function):
+    """torchvision Pool(MaxPool3d(k=(1,3,3), s=(1,2,2), p=(0,1,1))) on [B*N, C] tokens, class token bypass."""
+
+    @staticmethod
+    def forward(ctx, x, B, thw, kernel, stride, padding):
+        C = x.shape[1]
+        g = K.PoolGeom(B, 1, C, tuple(thw), tuple(kernel), tuple(stride), tuple(padding), True)
+        y, am = K.pool_fwd(x.view(B, g.n_in, 1, C), g, None, want_argmax=True)
+        ctx.save_for_backward(am)
+        ctx.g = g
+        return y.view(B * g.n_out, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (am,) = ctx.saved_tensors
+        g = ctx.g
+        dy4 = _c(dy).view(g.B, g.n_out, 1, g.C)
+        dx = torch.empty((g.B, g.n_in, 1, g.C), device=dy.device, dtype=dy.dtype)
+        K.pool_bwd_data(dy4, dx, g, None, am)
+        return dx.view(g.B * g.n_in, g.C), None, None, None, None, None
+
+
+def pool_skip(x, B, thw, kernel, stride, padding):
+    return PoolSkipFn.apply(x, B, thw, kernel, stride, padding)
+
+
+# -------------------------------------------------------------------------------- patch embedding
+class PatchEmbedFn(torch.autograd.Function):
+    """conv_proj (Conv3d 3->C, k(3,7,7) s(2,4,4) p(1,3,3)) + flatten/transpose + class-token concat
+    (models/video_encoder.py:237-241) as im2col + batched MFMA GEMM writing rows 1.. of each clip."""
+
+    @staticmethod
+    def forward(ctx, video, weight, bias, cls_token, dtype):
+        # video: [B', T, H, W, Cin] fp32 (NDHWC memory)
+        Bp = video.shape[0]
+        Cout, Cin, kt, kh, kw = weight.shape
+        stride, padding = (2, 4, 4), (1, 3, 3)
+        Kc = Cin * kt * kh * kw
+        Kp = 32 * ((Kc + 31) // 32)
+        col = K.im2col3d(_c(video), (kt, kh, kw), stride, padding, Kp, dtype)
+        L_ = col.shape[0] // Bp
+        # weight in (kt,kh,kw,cin) column order, zero padded (tiny host-side view op on 42k elements)
+        w2 = torch.zeros((Cout, Kp), device=video.device, dtype=torch.float32)
+        w2[:, :Kc] = weight.detach().permute(0, 2, 3, 4, 1).reshape(Cout, Kc)
+        wc = _as_dtype(w2, dtype)
+        out = torch.empty((Bp, L_ + 1, Cout), device=video.device, dtype=dtype)
+        K.gemm_batched(col, wc, out[:, 1:], M=L_, N=Cout, K=Kp, lda=Kp, ldb=Kp, ldc=Cout, batch=Bp, sA=L_ * Kp, sB=0,
+                       sC=(L_ + 1) * Cout, bias=bias.detach())
+        K.broadcast_row(_c(cls_token.detach()), out, (L_ + 1) * Cout, Bp)
+        ctx.save_for_backward(col)
+        ctx.meta = (Bp, L_, Cout, Cin, kt, kh, kw, Kc, Kp)
+        return out.view(Bp * (L_ + 1), Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (col,) = ctx.saved_tensors
+        Bp, L_, Cout, Cin, kt, kh, kw, Kc, Kp = ctx.meta
+        dy3 = _c(dy).view(Bp, L_ + 1, Cout)
+        dw = db = dcls = None
+        f32 = dict(device=dy.device, dtype=torch.float32)
+        dcls_sum = K.colsum(dy3.view(Bp, (L_ + 1) * Cout)[:, :Cout])
+        if ctx.needs_input_grad[3]:
+            dcls = dcls_sum
+        if ctx.needs_input_grad[1]:
+            # dW[c][k] = sum_b sum_l dy[b][1+l][c] * col[b][l][k]: batched k-major GEMM, atomically accumulated
+            dw2 = torch.zeros((Cout, Kp), **f32)
+            K.gemm_batched(dy3[:, 1:], col, dw2, M=Cout, N=Kp, K=L_, lda=Cout, ldb=Kp, ldc=Kp, batch=Bp,
+                           sA=(L_ + 1) * Cout, sB=L_ * Kp, sC=0, a_km=True, b_km=True, accumulate=True,
+                           splitk=max(1, min(64, 1024 // max(1, Bp))))
+            dw = dw2[:, :Kc].reshape(Cout, kt, kh, kw, Cin).permute(0, 4, 1, 2, 3).contiguous()
+        if ctx.needs_input_grad[2]:
+            db_all = K.colsum(dy3.view(Bp * (L_ + 1), Cout))
+            db = K.axpby(db_all, dcls_sum, 1.0, -1.0)
+        return None, dw, db, dcls, None
+
+
+def patch_embed(video, weight, bias, cls_token, dtype):
+    return PatchEmbedFn.apply(video, weight, bias, cls_token, dtype)
+
+
+# ----------------------------------------------------------------------------------- small ops
+class TokenMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.n = x.shape[1]
+        return K.token_mean(_c(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.token_mean(_c(dy), backward=True, n_tokens=ctx.n)
+
+
+def token_mean(x):
+    return TokenMeanFn.apply(x)
+
+
+class QPoolFn(torch.autograd.Function):
+    """softmax(<q, x_n>) weighted sum over n (EnhancedVideoAggregator tail), fp32."""
+
+    @staticmethod
+    def forward(ctx, x, q):
+        x = _c(x)
+        out, w = K.qpool_fwd(x, _c(q.detach()).view(-1))
+        ctx.save_for_backward(x, q.detach(), w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, q, w = ctx.saved_tensors
+        dx, dq = K.qpool_bwd(x, _c(q).view(-1), w, _c(dout))
+        return dx, dq.view(q.shape)
+
+
+def qpool(x, q):
+    return QPoolFn.apply(x, q)
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.axpby(_c(a), _c(b))
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+class CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return _as_dtype(x, dtype)
+
+    @staticmethod
+    def backward(ctx, d):
+        return _as_dtype(_c(d), ctx.src), None
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    return CastFn.apply(x, dtype)
+
+
+_DROPOUT_CALLS = 0
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return K.dropout(_c(x), p, seed)
+
+    @staticmethod
+    def backward(ctx, d):
+        return K.dropout(_c(d), ctx.p, ctx.seed), None, None
+
+
+def dropout(x, p: float, training: bool):
+    """nn.Dropout: identity in eval / p == 0; counter-hash keep mask otherwise (mask regenerated in backward)."""
+    global _DROPOUT_CALLS
+    if not training or p <= 0.0:
+        return x
+    _DROPOUT_CALLS += 1
+    seed = (torch.initial_seed() * 1000003 + _DROPOUT_CALLS) & (2**63 - 1)
+    return DropoutFn.apply(x, float(p), seed)
+
+
+class EmbedFn(torch.autograd.Function):
+    """BERT embeddings: word[ids] + position[s] + token_type[0] (fp32 tables -> compute dtype)."""
+
+    @staticmethod
+    def forward(ctx, ids, word, pos, typ, dtype):
+        ids = _c(ids)
+        out = K.embed_fwd(ids, word.detach(), pos.detach(), typ.detach(), dtype)
+        ctx.save_for_backward(ids)
+        ctx.shapes = (word.shape, pos.shape, typ.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        ws, ps, ts = ctx.shapes
+        f32 = dict(device=dy.device, dtype=torch.float32)
+        dword = torch.zeros(ws, **f32) if ctx.needs_input_grad[1] else None
+        dpos = torch.zeros(ps, **f32) if ctx.needs_input_grad[2] else None
+        dtyp = torch.zeros(ts, **f32) if ctx.needs_input_grad[3] else None
+        K.embed_bwd(ids, _c(dy), dword, dpos, dtyp)
+        return None, dword, dpos, dtyp, None
+
+
+def embed(ids, word, pos, typ, dtype):
+    return EmbedFn.apply(ids, word, pos, typ, dtype)
+
+
+# ------------------------------------------------------------------- nn.MultiheadAttention core
+def multihead_attention(query, key_value, in_w, in_b, out_w, out_b, num_heads: int, self_attn: bool):
+    """batch_first nn.MultiheadAttention forward (no masks, no attention dropout) built from our GEMM + attention.
+
+    query: [B, Lq, E]; key_value: [B, Lk, E] (key == value).  Weight slices are views of the packed in_proj
+    parameters, so gradients flow back to `in_proj_weight` / `in_proj_bias` through autograd's slicing.
+    """
+    B, Lq, E = query.shape
+    Lk = key_value.shape[1]
+    hd = E // num_heads
+    if self_attn:
+        qkv = linear(query, in_w, in_b).view(B, Lq, 3, num_heads, hd)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    else:
+        q = linear(query, in_w[:E], in_b[:E]).view(B, Lq, num_heads, hd)
+        kv = linear(key_value, in_w[E:], in_b[E:]).view(B, Lk, 2, num_heads, hd)
+        k, v = kv[:, :, 0], kv[:, :, 1]
+    ctx = attention(q, k, v, 1.0 / math.sqrt(hd))
+    return linear(ctx.reshape(B, Lq, E), out_w, out_b)

@@ -1,8 +1,12 @@
 """Thin, autograd-free Python wrappers over the C-ABI kernels (shape checks + launch).
 
-Every function here calls into `libdcc_hip.so`; there is no torch fallback.
+Every function here calls into `libdcc_hip.so` (include/dcc.h); there is no torch fallback.
+torch is used for device memory (allocation, views) and the current HIP stream only.
 """
 from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
 
 import torch
 
@@ -11,6 +15,15 @@ from . import _lib as L
 GEMM_BIAS, GEMM_GELU, GEMM_SAVE_PRE, GEMM_RESID, GEMM_DGELU, GEMM_ACCUM = 1, 2, 4, 8, 16, 32
 
 
+def _i64(vals):
+    return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def _i32(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+# ----------------------------------------------------------------------------------------- GEMM
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = False, bias: torch.Tensor | None = None,
          resid: torch.Tensor | None = None, aux: torch.Tensor | None = None, gelu: bool = False,
          save_pre: bool = False, dgelu: bool = False, out: torch.Tensor | None = None, accumulate: bool = False,
@@ -21,7 +34,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
     """
     L.require_cuda(a, b, bias, resid, aux, out)
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
-    assert a.dtype == b.dtype
+    assert a.dtype == b.dtype, (a.dtype, b.dtype)
     M, K = (a.shape[1], a.shape[0]) if a_km else (a.shape[0], a.shape[1])
     N, Kb = (b.shape[1], b.shape[0]) if b_km else (b.shape[0], b.shape[1])
     assert K == Kb, (a.shape, b.shape, a_km, b_km)
@@ -55,6 +68,25 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
     return out
 
 
+def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=None, a_km=False, b_km=False,
+                 alpha: float = 1.0, accumulate: bool = False, splitk: int = 1):
+    """Raw batched form (base tensors + explicit strides); `a`/`b`/`out` only provide base pointers and dtypes."""
+    L.require_cuda(a, b, out, bias)
+    flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_ACCUM if accumulate else 0)
+    L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), None, None, lda, ldb, ldc, 0, 0, M, N, K, batch, sA,
+           sB, sC, splitk, float(alpha), flags, int(a_km), int(b_km), L.dt(a), L.dt(out), L.stream())
+    return out
+
+
+def wgrad_splitk(rows: int, n: int, k: int) -> int:
+    """Split factor for weight-gradient GEMMs (reduction over `rows`, output n x k)."""
+    tiles = ((n + 127) // 128) * ((k + 127) // 128)
+    ksteps = (rows + 31) // 32
+    want = max(1, 1024 // tiles)
+    return int(max(1, min(want, ksteps // 4 if ksteps >= 8 else 1, 512)))
+
+
+# ------------------------------------------------------------------------------------ attention
 def _strides3(t: torch.Tensor) -> list[int]:
     assert t.dim() == 4 and t.stride(3) == 1, "attention operands are [B, N, H, D] views with unit inner stride"
     return [t.stride(0), t.stride(1), t.stride(2)]
@@ -63,8 +95,6 @@ def _strides3(t: torch.Tensor) -> list[int]:
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: float, kbias: torch.Tensor | None = None,
              residual: bool = False, res_start: int = 0):
     """O = softmax(scale * q k^T + kbias) v (+ q[..., :DV] for rows >= res_start). Returns (O [B,Nq,H,DV], LSE [B,H,Nq])."""
-    import ctypes
-
     L.require_cuda(q, k, v, kbias)
     B, Nq, H, DQK = q.shape
     Nk, DV = k.shape[1], v.shape[3]
@@ -73,7 +103,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: float,
     lse = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
     if kbias is not None:
         assert kbias.shape == (B, Nk) and kbias.dtype == torch.float32 and kbias.is_contiguous()
-    st = (ctypes.c_int64 * 12)(*(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o)))
+    st = _i64(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o))
     L.call("dcc_attn_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(kbias),
            L.ptr(q) if residual else None, int(res_start), st, B, H, Nq, Nk, DQK, DV, float(scale), L.dt(q), L.stream())
     return o, lse
@@ -81,9 +111,9 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: float,
 
 def attn_bwd(q, k, v, o, do, lse, *, scale: float, kbias=None, residual: bool = False, res_start: int = 0,
              qsplit: int | None = None):
-    """Gradients of attn_fwd w.r.t. q (attention path only; the residual's dq = do is the caller's), k, v."""
-    import ctypes
+    """Gradients of attn_fwd w.r.t. q (attention path only; the residual's dq = do is the caller's), k, v.
 
+    dk/dv come back in fp32 when the query range is split (atomic accumulation)."""
     L.require_cuda(q, k, v, o, do, lse)
     B, Nq, H, DQK = q.shape
     Nk, DV = k.shape[1], v.shape[3]
@@ -97,9 +127,369 @@ def attn_bwd(q, k, v, o, do, lse, *, scale: float, kbias=None, residual: bool = 
     dk = alloc((B, Nk, H, DQK), device=q.device, dtype=kv_dtype)
     dv = alloc((B, Nk, H, DV), device=q.device, dtype=kv_dtype)
     dvec = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
-    st = (ctypes.c_int64 * 21)(*(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o) + _strides3(dq) +
-                                 _strides3(dk) + _strides3(dv)))
+    st = _i64(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o) + _strides3(dq) + _strides3(dk) + _strides3(dv))
     L.call("dcc_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(dvec), L.ptr(kbias),
            L.ptr(q) if residual else None, int(res_start), L.ptr(dq), L.ptr(dk), L.ptr(dv), st, B, H, Nq, Nk, DQK, DV,
            float(scale), int(qsplit), L.dt(q), L.stream())
     return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x2d: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor | None = None):
+    """x2d: [rows, C] (row stride free). Returns (y, mean, rstd)."""
+    L.require_cuda(x2d, gamma, beta, out)
+    rows, C = x2d.shape
+    assert x2d.stride(1) == 1 and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    if out is None:
+        out = torch.empty((rows, C), device=x2d.device, dtype=x2d.dtype)
+    assert out.shape == (rows, C) and out.stride(1) == 1 and out.dtype == x2d.dtype
+    mean = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    L.call("dcc_layernorm_fwd", L.ptr(x2d), x2d.stride(0), L.ptr(out), out.stride(0), L.ptr(gamma), L.ptr(beta),
+           L.ptr(mean), L.ptr(rstd), rows, C, float(eps), L.dt(x2d), L.stream())
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dgamma, dbeta, dx: torch.Tensor | None = None):
+    """dgamma/dbeta (fp32) are accumulated into. dy2d may be fp32 while x is bf16; dx takes dy's dtype."""
+    L.require_cuda(dy2d, x2d, dx)
+    rows, C = x2d.shape
+    assert dy2d.shape == (rows, C) and dy2d.stride(1) == 1 and x2d.stride(1) == 1
+    if dx is None:
+        dx = torch.empty((rows, C), device=x2d.device, dtype=dy2d.dtype)
+    assert dx.dtype == dy2d.dtype and dx.stride(1) == 1
+    L.call("dcc_layernorm_bwd", L.ptr(dy2d), dy2d.stride(0), L.ptr(x2d), x2d.stride(0), L.ptr(mean), L.ptr(rstd),
+           L.ptr(gamma), L.ptr(dx), dx.stride(0), L.ptr(dgamma), L.ptr(dbeta), rows, C, L.dt(x2d), L.dt(dy2d),
+           L.stream())
+    return dx
+
+
+# ------------------------------------------------------------------------------- pooling / conv
+@dataclass(frozen=True)
+class PoolGeom:
+    B: int
+    H: int
+    C: int
+    thw: tuple[int, int, int]
+    kernel: tuple[int, int, int]
+    stride: tuple[int, int, int]
+    padding: tuple[int, int, int]
+    has_cls: bool = True
+
+    @property
+    def out_thw(self) -> tuple[int, int, int]:
+        return tuple((s + 2 * p - k) // st + 1 for s, p, k, st in zip(self.thw, self.padding, self.kernel, self.stride))
+
+    @property
+    def n_in(self) -> int:
+        t, h, w = self.thw
+        return t * h * w + int(self.has_cls)
+
+    @property
+    def n_out(self) -> int:
+        t, h, w = self.out_thw
+        return t * h * w + int(self.has_cls)
+
+    def dims(self):
+        return _i32([self.B, self.H, self.C, *self.thw, *self.kernel, *self.stride, *self.padding, int(self.has_cls)])
+
+
+def _pool_strides(x: torch.Tensor, y: torch.Tensor):
+    return _i64(_strides3(x) + _strides3(y))
+
+
+def pool_fwd(x: torch.Tensor, g: PoolGeom, weight: torch.Tensor | None, out: torch.Tensor | None = None,
+             want_argmax: bool = False):
+    """x: [B, N_in, H, C] view. weight: fp32 [C, taps] for the depthwise conv, None for max pooling."""
+    L.require_cuda(x, weight, out)
+    assert x.shape == (g.B, g.n_in, g.H, g.C), (x.shape, g)
+    if out is None:
+        out = torch.empty((g.B, g.n_out, g.H, g.C), device=x.device, dtype=x.dtype)
+    mode = 0 if weight is not None else 1
+    argmax = None
+    if mode == 1 and want_argmax:
+        argmax = torch.empty((g.B, g.n_out, g.H, g.C), device=x.device, dtype=torch.uint8)
+    if weight is not None:
+        assert weight.dtype == torch.float32 and weight.is_contiguous() and weight.numel() == g.C * g.kernel[0] * g.kernel[1] * g.kernel[2]
+    L.call("dcc_pool_fwd", L.ptr(x), L.ptr(out), L.ptr(weight), L.ptr(argmax), g.dims(), _pool_strides(x, out), mode,
+           L.dt(x), L.stream())
+    return out, argmax
+
+
+def pool_bwd_data(dy: torch.Tensor, dx: torch.Tensor, g: PoolGeom, weight: torch.Tensor | None,
+                  argmax: torch.Tensor | None = None):
+    """dx (a [B,N_in,H,C] view, e.g. a slice of the dqkv buffer) is overwritten."""
+    L.require_cuda(dy, dx, weight, argmax)
+    assert dy.shape == (g.B, g.n_out, g.H, g.C) and dx.shape == (g.B, g.n_in, g.H, g.C)
+    mode = 0 if weight is not None else 1
+    L.call("dcc_pool_bwd_data", L.ptr(dy), L.ptr(dx), L.ptr(weight), L.ptr(argmax), g.dims(), _pool_strides(dx, dy),
+           mode, L.dt(dx), L.dt(dy), L.stream())
+    return dx
+
+
+def dwconv_bwd_weight(dy: torch.Tensor, x: torch.Tensor, g: PoolGeom, dw: torch.Tensor):
+    """dw fp32 [C, taps] accumulated into."""
+    L.require_cuda(dy, x, dw)
+    assert dw.dtype == torch.float32 and dw.is_contiguous()
+    L.call("dcc_dwconv_bwd_weight", L.ptr(dy), L.ptr(x), L.ptr(dw), g.dims(), _pool_strides(x, dy), L.dt(x), L.dt(dy),
+           L.stream())
+    return dw
+
+
+def im2col3d(video: torch.Tensor, kernel, stride, padding, kp: int, dtype: torch.dtype) -> torch.Tensor:
+    """video: [B, T, H, W, C] fp32 contiguous -> [B*To*Ho*Wo, kp] in `dtype`, column order (kt,kh,kw,c)."""
+    L.require_cuda(video)
+    assert video.dtype == torch.float32 and video.is_contiguous() and video.dim() == 5
+    B, T, H, W, C = video.shape
+    To, Ho, Wo = [(s + 2 * p - k) // st + 1 for s, p, k, st in zip((T, H, W), padding, kernel, stride)]
+    col = torch.empty((B * To * Ho * Wo, kp), device=video.device, dtype=dtype)
+    L.call("dcc_im2col3d", L.ptr(video), L.ptr(col), B, T, H, W, C, *kernel, *stride, *padding, kp, L.dt(dtype),
+           L.stream())
+    return col
+
+
+# ------------------------------------------------------------------------------------- rel-pos
+def relpos_dims(B, H, D, A, q_thw, k_thw, has_cls=True):
+    return _i32([B, H, D, A, *q_thw, *k_thw, int(has_cls)])
+
+
+def relpos_tab_fwd(Qf, rel, idx, dims, scale):
+    L.require_cuda(Qf)
+    L.call("dcc_relpos_tab_fwd", L.ptr(Qf), L.ptr(rel[0]), L.ptr(rel[1]), L.ptr(rel[2]), L.ptr(idx[0]), L.ptr(idx[1]),
+           L.ptr(idx[2]), dims, _i64(_strides3(Qf)), float(scale), L.dt(Qf), L.stream())
+
+
+def relpos_kaug(Kf, dims):
+    L.require_cuda(Kf)
+    L.call("dcc_relpos_kaug", L.ptr(Kf), dims, _i64(_strides3(Kf)), L.dt(Kf), L.stream())
+
+
+def relpos_tab_bwd(Qf, dQf, dO, dq, rel, drel, idx, dims, scale):
+    L.require_cuda(Qf, dQf, dO, dq)
+    assert dQf.stride() == Qf.stride() and dq.is_contiguous()
+    L.call("dcc_relpos_tab_bwd", L.ptr(Qf), L.ptr(dQf), L.ptr(dO), _i64(_strides3(dO)) if dO is not None else None,
+           L.ptr(dq), L.ptr(rel[0]), L.ptr(rel[1]), L.ptr(rel[2]), L.ptr(drel[0]), L.ptr(drel[1]), L.ptr(drel[2]),
+           L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims, _i64(_strides3(Qf)), float(scale), L.dt(Qf), L.stream())
+
+
+# ---------------------------------------------------------------------------------- elementwise
+def cast(src: torch.Tensor, dtype: torch.dtype, out: torch.Tensor | None = None) -> torch.Tensor:
+    L.require_cuda(src, out)
+    assert src.is_contiguous()
+    if out is None:
+        out = torch.empty(src.shape, device=src.device, dtype=dtype)
+    assert out.is_contiguous() and out.numel() == src.numel()
+    if src.numel():
+        L.call("dcc_cast", L.ptr(src), L.ptr(out), src.numel(), L.dt(src), L.dt(out), L.stream())
+    return out
+
+
+def cast2d(src: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """Strided 2-D copy/cast: both [rows, cols] with unit inner stride."""
+    L.require_cuda(src, out)
+    assert src.dim() == 2 and out.shape == src.shape and src.stride(1) == 1 and out.stride(1) == 1
+    L.call("dcc_cast2d", L.ptr(src), src.stride(0), L.ptr(out), out.stride(0), src.shape[0], src.shape[1], L.dt(src),
+           L.dt(out), L.stream())
+    return out
+
+
+def axpby(x: torch.Tensor, y: torch.Tensor | None = None, a: float = 1.0, b: float = 1.0,
+          out: torch.Tensor | None = None) -> torch.Tensor:
+    L.require_cuda(x, y, out)
+    assert x.is_contiguous() and (y is None or (y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype))
+    if out is None:
+        out = torch.empty_like(x)
+    L.call("dcc_axpby", L.ptr(out), float(a), L.ptr(x), float(b), L.ptr(y), x.numel(), L.dt(x), L.stream())
+    return out
+
+
+def dgelu_mul(dy: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:
+    L.require_cuda(dy, pre)
+    assert dy.is_contiguous() and pre.is_contiguous() and dy.shape == pre.shape and dy.dtype == pre.dtype
+    out = torch.empty_like(dy)
+    L.call("dcc_dgelu_mul", L.ptr(dy), L.ptr(pre), L.ptr(out), dy.numel(), L.dt(dy), L.stream())
+    return out
+
+
+def colsum(x2d: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out[n] (+)= sum_m x[m,n]; out fp32 (zero-initialised when not given)."""
+    L.require_cuda(x2d, out)
+    assert x2d.dim() == 2 and x2d.stride(1) == 1
+    M, N = x2d.shape
+    if out is None:
+        out = torch.zeros(N, device=x2d.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.numel() == N
+    L.call("dcc_colsum", L.ptr(x2d), x2d.stride(0), L.ptr(out), M, N, L.dt(x2d), L.stream())
+    return out
+
+
+def broadcast_row(src: torch.Tensor, dst: torch.Tensor, ld: int, rows: int):
+    L.require_cuda(src, dst)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    L.call("dcc_broadcast_row", L.ptr(src), L.ptr(dst), ld, rows, src.numel(), L.dt(dst), L.stream())
+
+
+def token_mean(x: torch.Tensor, backward: bool = False, n_tokens: int | None = None) -> torch.Tensor:
+    """forward: [B,N,D] -> [B,D]; backward: dy [B,D] -> dx [B,n_tokens,D]."""
+    L.require_cuda(x)
+    assert x.is_contiguous()
+    if not backward:
+        B, N, D = x.shape
+        out = torch.empty((B, D), device=x.device, dtype=x.dtype)
+    else:
+        B, D = x.shape
+        N = int(n_tokens)
+        out = torch.empty((B, N, D), device=x.device, dtype=x.dtype)
+    L.call("dcc_token_mean", L.ptr(x), L.ptr(out), B, N, D, int(backward), L.dt(x), L.stream())
+    return out
+
+
+def embed_fwd(ids, word, pos, type_, dtype) -> torch.Tensor:
+    L.require_cuda(ids, word, pos, type_)
+    B, S = ids.shape
+    D = word.shape[1]
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    out = torch.empty((B * S, D), device=ids.device, dtype=dtype)
+    L.call("dcc_embed_fwd", L.ptr(ids), L.ptr(word), L.ptr(pos), L.ptr(type_), L.ptr(out), B * S, S, D, word.shape[0],
+           L.dt(dtype), L.stream())
+    return out
+
+
+def embed_bwd(ids, dy, dword, dpos, dtype0):
+    L.require_cuda(ids, dy, dword, dpos, dtype0)
+    B, S = ids.shape
+    D = dy.shape[-1]
+    vocab = dword.shape[0] if dword is not None else 1 << 30
+    L.call("dcc_embed_bwd", L.ptr(ids), L.ptr(dy), L.ptr(dword), L.ptr(dpos), L.ptr(dtype0), B * S, S, D, vocab,
+           L.dt(dy), L.stream())
+
+
+def rope(x: torch.Tensor, y: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, backward: bool = False):
+    """x, y: [B,N,H,D] views (y may alias x); tables [N,D] fp32."""
+    L.require_cuda(x, y, cos_t, sin_t)
+    B, N, H, D = x.shape
+    assert cos_t.shape == (N, D) and sin_t.shape == (N, D) and cos_t.is_contiguous() and sin_t.is_contiguous()
+    L.call("dcc_rope", L.ptr(x), L.ptr(y), L.ptr(cos_t), L.ptr(sin_t), B, N, H, D, _i64(_strides3(x) + _strides3(y)),
+           int(backward), L.dt(x), L.stream())
+    return y
+
+
+def qpool_fwd(x: torch.Tensor, q: torch.Tensor):
+    L.require_cuda(x, q)
+    B, N, D = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and q.numel() == D
+    out = torch.empty((B, D), device=x.device, dtype=torch.float32)
+    w = torch.empty((B, N), device=x.device, dtype=torch.float32)
+    L.call("dcc_qpool_fwd", L.ptr(x), L.ptr(q), L.ptr(out), L.ptr(w), B, N, D, L.stream())
+    return out, w
+
+
+def qpool_bwd(x, q, w, dout):
+    L.require_cuda(x, q, w, dout)
+    B, N, D = x.shape
+    dx = torch.empty_like(x)
+    dq = torch.zeros(D, device=x.device, dtype=torch.float32)
+    L.call("dcc_qpool_bwd", L.ptr(x), L.ptr(q), L.ptr(w), L.ptr(dout.contiguous()), L.ptr(dx), L.ptr(dq), B, N, D,
+           L.stream())
+    return dx, dq
+
+
+def nan_to_num_(x: torch.Tensor, nan: float = 0.0, posinf: float = 0.0, neginf: float = 0.0,
+                count: torch.Tensor | None = None) -> torch.Tensor:
+    L.require_cuda(x, count)
+    assert x.is_contiguous()
+    if x.numel():
+        L.call("dcc_nan_to_num", L.ptr(x), x.numel(), float(nan), float(posinf), float(neginf), L.ptr(count), L.dt(x),
+               L.stream())
+    return x
+
+
+def dropout(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    L.require_cuda(x)
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    L.call("dcc_dropout", L.ptr(x), L.ptr(out), x.numel(), float(p), ctypes.c_uint64(seed & (2**64 - 1)), L.dt(x),
+           L.stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------- loss
+def l2norm_fwd(x: torch.Tensor, eps: float = 1e-12, norm_sum: torch.Tensor | None = None):
+    L.require_cuda(x, norm_sum)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    R, D = x.shape
+    y = torch.empty((R, D), device=x.device, dtype=torch.float32)
+    norms = torch.empty(R, device=x.device, dtype=torch.float32)
+    L.call("dcc_l2norm_fwd", L.ptr(x), x.stride(0), L.ptr(y), L.ptr(norms), R, D, float(eps), L.ptr(norm_sum), L.stream())
+    return y, norms
+
+
+def l2norm_bwd(dy, y, norms, eps: float = 1e-12):
+    L.require_cuda(dy, y, norms)
+    R, D = y.shape
+    dx = torch.empty_like(y)
+    L.call("dcc_l2norm_bwd", L.ptr(dy), L.ptr(y), L.ptr(norms), L.ptr(dx), D, R, D, float(eps), L.stream())
+    return dx
+
+
+def logits_fwd(sim, mode: int, log_temp, clamp_temp: bool, bias=None, col_margin=None):
+    L.require_cuda(sim, log_temp, bias, col_margin)
+    B, M = sim.shape
+    z = torch.empty_like(sim)
+    L.call("dcc_logits_fwd", L.ptr(sim), L.ptr(z), B, M, mode, L.ptr(log_temp), int(clamp_temp), L.ptr(bias),
+           L.ptr(col_margin), L.stream())
+    return z
+
+
+def logits_bwd(sim, dz, mode: int, log_temp, clamp_temp: bool, bias, scal):
+    L.require_cuda(sim, dz, log_temp, scal)
+    B, M = sim.shape
+    dsim = torch.empty_like(sim)
+    L.call("dcc_logits_bwd", L.ptr(sim), L.ptr(dz), L.ptr(dsim), B, M, mode, L.ptr(log_temp), int(clamp_temp),
+           L.ptr(bias), L.ptr(scal), L.stream())
+    return dsim
+
+
+def lse(z, rows: bool = True, cols: bool = True):
+    L.require_cuda(z)
+    B, M = z.shape
+    lr = torch.empty(B, device=z.device, dtype=torch.float32) if rows else None
+    lc = torch.empty(M, device=z.device, dtype=torch.float32) if cols else None
+    L.call("dcc_lse", L.ptr(z), L.ptr(lr), L.ptr(lc), B, M, L.stream())
+    return lr, lc
+
+
+def ce_diag(z, lr, lc, smooth: float, scal, want_grad: bool = True, sim=None):
+    L.require_cuda(z, lr, lc, scal, sim)
+    B = z.shape[0]
+    assert z.shape == (B, B)
+    dz = torch.empty_like(z) if want_grad else None
+    L.call("dcc_ce_diag", L.ptr(z), L.ptr(lr), L.ptr(lc), L.ptr(dz), B, float(smooth), L.ptr(scal), L.ptr(sim), L.stream())
+    return dz
+
+
+def rowcol_sums(w):
+    L.require_cuda(w)
+    B, M = w.shape
+    rs = torch.zeros(B, device=w.device, dtype=torch.float32)
+    cs = torch.zeros(M, device=w.device, dtype=torch.float32)
+    L.call("dcc_rowcol_sums", L.ptr(w), L.ptr(rs), L.ptr(cs), B, M, L.stream())
+    return rs, cs
+
+
+def weighted_ce(z, pos, lr, lc, rs, cs, eps: float, scal, want_grad: bool = True):
+    L.require_cuda(z, pos, scal)
+    B, M = z.shape
+    dz = torch.empty_like(z) if want_grad else None
+    L.call("dcc_weighted_ce", L.ptr(z), L.ptr(pos), L.ptr(lr), L.ptr(lc), L.ptr(rs), L.ptr(cs), L.ptr(dz), B, M,
+           float(eps), L.ptr(scal), L.stream())
+    return dz
+
+
+def bce(z, y, pw, pos_weight: float, neg_weight: float, thr: float, denom_host: float, denom_dev, scal,
+        want_grad: bool = True):
+    L.require_cuda(z, y, pw, denom_dev, scal)
+    dz = torch.empty_like(z) if want_grad else None
+    L.call("dcc_bce", L.ptr(z), L.ptr(y), L.ptr(pw), float(pos_weight), float(neg_weight), float(thr),
+           float(denom_host), L.ptr(denom_dev), L.ptr(dz), z.numel(), L.ptr(scal), L.stream())
+    return dz

@@ -1,0 +1,283 @@
+"""Contrastive losses with the reference's class names / registry names, computed by HIP kernels (csrc/loss.hip +
+the fp32 MFMA GEMM).  Reference: utils/loss/losses.py:12-331, utils/loss/contrastive.py:108-319,
+utils/loss/weighted_siglip.py:6-51, utils/loss/typing.py:20-39.
+
+One fused autograd node per loss: forward computes loss AND the closed-form gradients w.r.t. both embedding
+matrices, log_temp and the SigLIP bias (the similarity matrix is needed for both anyway), backward only rescales
+them by the upstream scalar.  DDP variants all-gather the embeddings first (RCCL through torch.distributed) and
+keep the reference's gradient convention: each rank back-propagates its own rows of the global loss
+(GatherLayer.backward, utils/loss/losses.py:85-93).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib as L
+from . import kernels as K
+from .registry import LossRegistry
+
+MODE_PLAIN, MODE_GATED, MODE_BIAS_CLAMP = 0, 1, 2
+KIND_CE, KIND_WEIGHTED_CE, KIND_BCE = 0, 1, 2
+
+
+def _scale_by(x: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
+    L.call("dcc_scale_by_dev", L.ptr(x), x.numel(), L.ptr(coef), L.stream())
+    return x
+
+
+class PairLossFn(torch.autograd.Function):
+    """loss(normalize(v) normalize(t)^T transformed by log_temp/bias) with analytic gradients."""
+
+    @staticmethod
+    def forward(ctx, v, t, log_temp, bias, opts):
+        L.require_cuda(v, t, log_temp)
+        v32, t32 = v.detach(), t.detach()
+        if v.dtype != torch.float32:
+            v32 = K.cast(v.detach().contiguous(), torch.float32)
+        if t.dtype != torch.float32:
+            t32 = K.cast(t.detach().contiguous(), torch.float32)
+        v32, t32 = v32.contiguous(), t32.contiguous()
+        B, D = v32.shape
+        M = t32.shape[0]
+        mode, kind = opts["mode"], opts["kind"]
+        lt = log_temp.detach().reshape(-1)[:1].contiguous().float()
+        bs = bias.detach().reshape(-1)[:1].contiguous().float() if bias is not None else None
+        scal = torch.zeros(8, device=v.device, dtype=torch.float32)
+        vh, vn = K.l2norm_fwd(v32, norm_sum=scal[5:6])
+        th, tn = K.l2norm_fwd(t32, norm_sum=scal[6:7])
+        sim = K.gemm(vh, th)  # [B, M] cosine similarities, fp32 MFMA
+        z = K.logits_fwd(sim, mode, lt, opts.get("clamp_temp", False), bs, opts.get("col_margin"))
+        want_grad = any(ctx.needs_input_grad[:4])
+        lr = lc = None
+        if kind == KIND_CE:
+            if B != M:
+                raise ValueError(f"diagonal-target cross entropy needs as many texts as videos, got {B} x {M}")
+            lr, lc = K.lse(z)
+            dz = K.ce_diag(z, lr, lc, opts.get("label_smoothing", 0.0), scal, want_grad, sim=sim)
+        elif kind == KIND_WEIGHTED_CE:
+            pos = opts["pos"].contiguous().float()
+            lr, lc = K.lse(z)
+            rs, cs = K.rowcol_sums(pos)
+            dz = K.weighted_ce(z, pos, lr, lc, rs, cs, opts.get("eps", 1e-6), scal, want_grad)
+        else:
+            y = opts["targets"].contiguous().float()
+            pw = opts.get("pos_weights")
+            pw = pw.contiguous().float() if pw is not None else None
+            dz = K.bce(z, y, pw, opts.get("positive_weight", 1.0), opts.get("negative_weight", 1.0), opts.get("thr", 0.5),
+                       opts.get("denom_host", float(B * M)), opts.get("denom_dev"), scal, want_grad)
+        if opts.get("diag_out") is not None:  # runner diagnostics (no extra GEMM / no extra host sync)
+            opts["diag_out"].update({"sim": sim, "logits": z, "lse_rows": lr, "scal": scal, "video_norms": vn,
+                                     "text_norms": tn})
+        if want_grad:
+            dsim = K.logits_bwd(sim, dz, mode, lt, opts.get("clamp_temp", False), bs, scal)
+            dvh = K.gemm(dsim, th, b_km=True)
+            dth = K.gemm(dsim, vh, a_km=True, b_km=True)
+            dv = K.l2norm_bwd(dvh, vh, vn)
+            dt = K.l2norm_bwd(dth, th, tn)
+            ctx.save_for_backward(dv, dt, scal)
+        ctx.shapes = (log_temp.shape, bias.shape if bias is not None else None, v.dtype, t.dtype)
+        return scal[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        dv, dt, scal = ctx.saved_tensors
+        lt_shape, b_shape, vdt, tdt = ctx.shapes
+        g = g.detach().reshape(1).float().contiguous()
+        dv = _scale_by(dv, g)
+        dt = _scale_by(dt, g)
+        sc = _scale_by(scal.clone(), g)
+        dlt = sc[1].reshape(lt_shape) if ctx.needs_input_grad[2] else None
+        db = sc[2].reshape(b_shape) if (b_shape is not None and ctx.needs_input_grad[3]) else None
+        if vdt != torch.float32:
+            dv = K.cast(dv, vdt)
+        if tdt != torch.float32:
+            dt = K.cast(dt, tdt)
+        return dv, dt, dlt, db, None
+
+
+def pair_loss(v, t, log_temp, bias=None, **opts):
+    return PairLossFn.apply(v, t, log_temp, bias, opts)
+
+
+# ------------------------------------------------------------------------------------------ DDP gather
+class GatherLayer(torch.autograd.Function):
+    """all_gather that keeps the local rows' gradient (utils/loss/losses.py:70-93, utils/loss/contrastive.py:75-101).
+    One RCCL all_gather_into_tensor instead of world_size point copies + cat."""
+
+    @staticmethod
+    def forward(ctx, tensor: torch.Tensor) -> torch.Tensor:
+        if not (dist.is_available() and dist.is_initialized()):
+            return tensor
+        world = dist.get_world_size()
+        t = tensor.contiguous()
+        out = torch.empty((world * t.shape[0], *t.shape[1:]), device=t.device, dtype=t.dtype)
+        dist.all_gather_into_tensor(out, t)
+        ctx.rows = t.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output: torch.Tensor) -> torch.Tensor:
+        if not (dist.is_available() and dist.is_initialized()):
+            return grad_output
+        r = dist.get_rank()
+        return grad_output[r * ctx.rows:(r + 1) * ctx.rows]
+
+
+def gather_all(tensor: torch.Tensor) -> torch.Tensor:
+    if not (dist.is_available() and dist.is_initialized()):
+        return tensor
+    return GatherLayer.apply(tensor)
+
+
+gather_with_gradient = gather_all
+_DEFAULT_LOG_TEMP = torch.log(torch.tensor(0.1))
+
+
+def _lt(log_temp, ref):
+    if log_temp is None:
+        log_temp = _DEFAULT_LOG_TEMP
+    return log_temp if log_temp.is_cuda else log_temp.to(ref.device)
+
+
+@LossRegistry.register("contrastive")
+class ContrastiveLoss(nn.Module):
+    """CLIP-style bidirectional InfoNCE on the local batch (utils/loss/losses.py:12-64)."""
+
+    def forward(self, video_features, text_features, log_temp=None):
+        return pair_loss(video_features, text_features, _lt(log_temp, video_features), mode=MODE_PLAIN, kind=KIND_CE)
+
+
+@LossRegistry.register("contrastive_ddp")
+class ContrastiveLossDDP(nn.Module):
+    """Global-batch InfoNCE: gather both sides, then as ContrastiveLoss (utils/loss/losses.py:104-158)."""
+
+    def forward(self, video_features, text_features, log_temp=None):
+        v, t = gather_all(video_features), gather_all(text_features)
+        return pair_loss(v, t, _lt(log_temp, video_features), mode=MODE_PLAIN, kind=KIND_CE)
+
+
+@LossRegistry.register("clip")
+class CLIPLoss(nn.Module):
+    """utils/loss/contrastive.py:108-164: auto-DDP gather, temperature clamp(min=1e-4), label smoothing."""
+
+    def __init__(self, label_smoothing: float = 0.0):
+        super().__init__()
+        self.label_smoothing = label_smoothing
+
+    def forward(self, video_features, text_features, log_temp):
+        v, t = gather_all(video_features), gather_all(text_features)
+        return pair_loss(v, t, _lt(log_temp, video_features), mode=MODE_PLAIN, kind=KIND_CE, clamp_temp=True,
+                         label_smoothing=self.label_smoothing)
+
+
+@LossRegistry.register("siglip")
+class SiglipLoss(nn.Module):
+    """"Gated softmax": sim * sigmoid(sim) / temp, then bidirectional CE (utils/loss/losses.py:160-211)."""
+
+    def forward(self, video_features, text_features, log_temp=None):
+        return pair_loss(video_features, text_features, _lt(log_temp, video_features), mode=MODE_GATED, kind=KIND_CE)
+
+
+@LossRegistry.register("siglip_ddp")
+class SiglipLossDDP(nn.Module):
+    """utils/loss/losses.py:213-276 (the reference gathers in fp16 to cut traffic; we gather bf16-rounded values
+    only when the embeddings already are bf16, otherwise fp32 — 1 MB per rank at B=512 is latency-bound anyway)."""
+
+    def forward(self, video_features, text_features, log_temp=None):
+        v, t = gather_all(video_features), gather_all(text_features)
+        return pair_loss(v, t, _lt(log_temp, video_features), mode=MODE_GATED, kind=KIND_CE)
+
+
+@LossRegistry.register("InfoNCE")
+class InfoNCELoss(nn.Module):
+    """Dispatcher with its own temperature parameter (utils/loss/losses.py:278-331)."""
+
+    def __init__(self, temperature: float = 0.07, use_ddp: bool = False, loss_type: str = "contrastive"):
+        super().__init__()
+        self.temperature, self.use_ddp, self.loss_type = temperature, use_ddp, loss_type
+        self.log_temp = nn.Parameter(torch.log(torch.tensor(temperature)))
+
+    def forward(self, video_features, text_features, log_temp=None):
+        temp = log_temp if log_temp is not None else self.log_temp
+        ddp = self.use_ddp and dist.is_available() and dist.is_initialized()
+        if self.loss_type == "siglip":
+            return (SiglipLossDDP() if ddp else SiglipLoss())(video_features, text_features, temp)
+        if self.loss_type == "contrastive":
+            return (ContrastiveLossDDP() if ddp else ContrastiveLoss())(video_features, text_features, temp)
+        raise ValueError(f"Invalid loss type: {self.loss_type}")
+
+
+@LossRegistry.register("siglip_pairwise")
+@LossRegistry.register("siglip2_bce")
+@LossRegistry.register("siglip2_bce_ddp")
+@LossRegistry.register("siglip2_multi_positive")
+class SigLIPLoss(nn.Module):
+    """Sigmoid-BCE pair classification with learnable bias, clamp(+-30), multi-positive masks and severity weights
+    (utils/loss/contrastive.py:171-319).  Under DDP the reference gathers only the video side (SURVEY §5 defect
+    note); world size 1 is the parity oracle, and for W > 1 we solve the symmetric global problem (both sides
+    gathered; pos_mask / pos_weights, if given, must already be global [Bg, Tg])."""
+
+    def __init__(self, bias_init: float = -10.0, learnable_bias: bool = True, positive_weight: float = 1.0,
+                 negative_weight: float = 1.0, use_severity_weights: bool = True, auto_balance: bool = False,
+                 entropy_regularization: bool = False, entropy_weight: float = 0.1, min_entropy_threshold: float = 2.0):
+        super().__init__()
+        self.positive_weight = max(float(positive_weight), 1e-6)
+        self.negative_weight = max(float(negative_weight), 1e-6)
+        self.use_severity_weights = use_severity_weights
+        if auto_balance or entropy_regularization:
+            raise NotImplementedError("auto_balance / entropy_regularization are off by default in the reference and "
+                                      "not implemented on the HIP path")
+        self.auto_balance, self.entropy_regularization = auto_balance, entropy_regularization
+        self.entropy_weight, self.min_entropy_threshold = entropy_weight, min_entropy_threshold
+        if learnable_bias:
+            self.bias = nn.Parameter(torch.tensor(bias_init))
+        else:
+            self.register_buffer("bias", torch.tensor(bias_init))
+
+    def forward(self, video_features, text_features, log_temp, pos_mask=None, pos_weights=None):
+        v, t = gather_all(video_features), text_features
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = gather_all(text_features)
+        B, T = v.shape[0], t.shape[0]
+        if pos_mask is None:
+            m = min(B, T)
+            targets = torch.zeros((B, T), device=v.device, dtype=torch.float32)
+            targets[:m, :m] = torch.eye(m, device=v.device)  # constant target construction (no arithmetic on data)
+        else:
+            targets = pos_mask.float().clamp(0.0, 1.0)
+        pw = pos_weights if (self.use_severity_weights and pos_weights is not None) else None
+        bias = self.bias if self.bias.is_cuda else self.bias.to(v.device)
+        return pair_loss(v, t, _lt(log_temp, v), bias, mode=MODE_BIAS_CLAMP, kind=KIND_BCE, clamp_temp=True,
+                         targets=targets, pos_weights=pw, positive_weight=self.positive_weight,
+                         negative_weight=self.negative_weight, thr=0.5, denom_host=float(B * T))
+
+
+class WeightedSigLIPLoss(nn.Module):
+    """utils/loss/weighted_siglip.py:6-51 on precomputed logits is used by the runner; here the fused form takes the
+    embeddings (gated logits) so that the whole multi-positive branch is one node (see runner.py)."""
+
+    def __init__(self, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.eps = eps
+
+    def forward(self, video_features, text_features, log_temp, positive_weights, col_margin=None):
+        if positive_weights.shape != (video_features.shape[0], text_features.shape[0]):
+            raise ValueError(f"positive_weights shape {tuple(positive_weights.shape)} must match logits shape "
+                             f"{(video_features.shape[0], text_features.shape[0])}.")
+        return pair_loss(video_features, text_features, log_temp, mode=MODE_GATED, kind=KIND_WEIGHTED_CE,
+                         pos=positive_weights, eps=self.eps, col_margin=col_margin)
+
+
+@dataclass
+class Loss:
+    """utils/loss/typing.py:20-39 — the loss plug-in boundary used by the project/runner."""
+
+    loss_type: Any
+
+    def run(self, **kwargs):
+        return self.loss_type(**kwargs)

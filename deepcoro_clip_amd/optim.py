@@ -1,0 +1,163 @@
+"""Step tail on HIP kernels: global gradient-norm clipping and AdamW (reference: runners/
+video_constrative_learning_runner.py:1398-1421 — `clip_grad_norm_` over both encoders, `optimizer.step()`).
+
+`HipAdamW` is a `torch.optim.Optimizer` with AdamW's constructor / param_groups / state layout
+(`step`, `exp_avg`, `exp_avg_sq`), so schedulers, checkpoints and the project's per-group learning rates work
+unchanged; `adopt(optimizer)` wraps an existing `torch.optim.AdamW/Adam` instance the project already built.
+One multi-tensor launch per phase, no host synchronisation (the clip coefficient stays on the device).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Iterable
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import functional as Fn
+
+OPT_CHUNK = 4096  # DCC_OPT_CHUNK
+
+_DESC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("shadow", "<u8"), ("n", "<i8"),
+                  ("lr", "<f4"), ("beta1", "<f4"), ("beta2", "<f4"), ("eps", "<f4"), ("wd", "<f4"), ("bc1", "<f4"),
+                  ("bc2", "<f4"), ("flags", "<i4")])
+assert _DESC.itemsize == 80
+
+
+class _TensorTable:
+    """Device-side descriptor table + (tensor, chunk) work list for a fixed list of parameters."""
+
+    def __init__(self, params: list[torch.Tensor]):
+        self.params = params
+        self.device = params[0].device
+        work = []
+        for i, p in enumerate(params):
+            for c in range((p.numel() + OPT_CHUNK - 1) // OPT_CHUNK):
+                work.append((i, c))
+        self.nblocks = len(work)
+        self.work = torch.tensor(work, dtype=torch.int32).reshape(-1, 2).to(self.device)
+        nbytes = len(params) * _DESC.itemsize
+        # two pinned staging buffers + events: a buffer is only rewritten after its previous H2D copy completed
+        self.hosts = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.events = [None, None]
+        self.turn = 0
+        self.dev = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+
+    def upload(self, desc: np.ndarray):
+        i = self.turn
+        self.turn ^= 1
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        self.hosts[i].numpy().view(_DESC)[:] = desc
+        self.dev.copy_(self.hosts[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.events[i] = ev
+
+
+def _grad_ptr(p: torch.Tensor) -> int:
+    g = p.grad
+    if g is None:
+        return 0
+    if g.dtype != torch.float32 or not g.is_contiguous():
+        raise L.DccError("HIP optimizer expects contiguous fp32 gradients")
+    return g.data_ptr()
+
+
+class GradClipper:
+    """torch.nn.utils.clip_grad_norm_(params, max_norm) semantics: grads scaled in place by
+    min(1, max_norm / (total_norm + 1e-6)); returns the total norm as a DEVICE tensor (no sync)."""
+
+    def __init__(self, params: Iterable[torch.Tensor]):
+        self.params = [p for p in params]
+        L.require_cuda(*self.params[:1])
+        self.table = _TensorTable(self.params)
+        dev = self.table.device
+        self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
+        self.coef = torch.ones(1, device=dev, dtype=torch.float32)
+        self.norm = torch.zeros(1, device=dev, dtype=torch.float32)
+
+    def _desc(self) -> np.ndarray:
+        d = np.zeros(len(self.params), dtype=_DESC)
+        for i, p in enumerate(self.params):
+            d[i]["g"] = _grad_ptr(p)
+            d[i]["n"] = p.numel()
+        return d
+
+    def clip_(self, max_norm: float) -> torch.Tensor:
+        t = self.table
+        t.upload(self._desc())
+        self.sumsq.zero_()
+        L.call("dcc_grad_sumsq", L.ptr(t.dev), L.ptr(t.work), t.nblocks, L.ptr(self.sumsq), L.stream())
+        L.call("dcc_clip_coef", L.ptr(self.sumsq), float(max_norm), L.ptr(self.coef), L.ptr(self.norm), L.stream())
+        L.call("dcc_scale_grads", L.ptr(t.dev), L.ptr(t.work), t.nblocks, L.ptr(self.coef), L.stream())
+        return self.norm
+
+
+class HipAdamW(torch.optim.Optimizer):
+    """AdamW (decoupled weight decay) / Adam (adamw=False) with torch's state layout, updated by `dcc_adam_step`."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 adamw: bool = True):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, adamw=adamw)
+        super().__init__(params, defaults)
+        self._table: _TensorTable | None = None
+        self._plist: list[torch.Tensor] = []
+
+    @classmethod
+    def adopt(cls, optimizer: torch.optim.Optimizer) -> "HipAdamW":
+        """Re-home the param_groups / state of an existing torch Adam/AdamW (same hyper-parameters, same state)."""
+        if isinstance(optimizer, HipAdamW):
+            return optimizer
+        if not isinstance(optimizer, (torch.optim.AdamW, torch.optim.Adam)):
+            raise L.DccError(f"HipAdamW.adopt supports torch.optim.Adam/AdamW, got {type(optimizer).__name__}")
+        adamw = isinstance(optimizer, torch.optim.AdamW) or bool(optimizer.defaults.get("decoupled_weight_decay", False))
+        for g in optimizer.param_groups:
+            if g.get("amsgrad") or g.get("maximize"):
+                raise L.DccError("amsgrad / maximize are not supported by the HIP AdamW")
+        self = cls.__new__(cls)
+        torch.optim.Optimizer.__init__(self, optimizer.param_groups, dict(optimizer.defaults, adamw=adamw))
+        self.state = optimizer.state
+        for g in self.param_groups:
+            g.setdefault("adamw", adamw)
+        self._table, self._plist = None, []
+        return self
+
+    def _build(self):
+        self._plist = [p for g in self.param_groups for p in g["params"]]
+        L.require_cuda(*self._plist[:1])
+        self._table = _TensorTable(self._plist)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: torch.Tensor | None = None):
+        loss = closure() if closure is not None else None
+        if self._table is None or len(self._plist) != sum(len(g["params"]) for g in self.param_groups):
+            self._build()
+        d = np.zeros(len(self._plist), dtype=_DESC)
+        i = 0
+        for g in self.param_groups:
+            b1, b2 = g["betas"]
+            for p in g["params"]:
+                gp = _grad_ptr(p) if p.requires_grad else 0
+                if gp:
+                    st = self.state[p]
+                    if len(st) == 0:
+                        st["step"] = torch.tensor(0.0)
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["step"] = st["step"] + 1 if torch.is_tensor(st["step"]) else st["step"] + 1
+                    k = float(st["step"])
+                    d[i] = (p.data_ptr(), gp, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), 0, p.numel(),
+                            float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], 1.0 - b1 ** k, 1.0 - b2 ** k,
+                            1 if g.get("adamw", True) else 0)
+                    if not p.is_contiguous():
+                        raise L.DccError("HIP optimizer expects contiguous parameters")
+                else:
+                    d[i]["n"] = p.numel()
+                i += 1
+        t = self._table
+        t.upload(d)
+        L.call("dcc_adam_step", L.ptr(t.dev), L.ptr(t.work), t.nblocks, L.ptr(grad_scale), L.stream())
+        Fn.invalidate_weight_cache()  # parameters changed behind autograd's version counters
+        return loss

@@ -1,0 +1,63 @@
+"""Registries with the reference's names (utils/registry.py:13-94, utils/enums.py:33-79) so that
+`ModelRegistry.get("video_encoder")`, `LossRegistry.get("contrastive")`, `RunnerRegistry.get("DeepCORO_clip")`
+resolve to the HIP-backed classes of this package."""
+from __future__ import annotations
+
+import importlib
+import pkgutil
+from typing import Any, Dict, Optional, Type
+
+
+class BaseRegistry:
+    _registry: Dict[str, Type[Any]] = {}
+    _registry_type: str = "base"
+
+    @classmethod
+    def register(cls, name: str):
+        def decorator(class_type: Type[Any]) -> Type[Any]:
+            cls._registry[str(name)] = class_type
+            return class_type
+
+        return decorator
+
+    @classmethod
+    def get(cls, name: str) -> Optional[Type[Any]]:
+        name = str(name)
+        if name not in cls._registry:
+            raise ValueError(
+                f"{cls._registry_type} {name} not found in registry {cls._registry_type}. "
+                f"Available {cls._registry_type}s: {list(cls._registry.keys())}"
+            )
+        return cls._registry[name]
+
+    @classmethod
+    def list_registered(cls) -> Dict[str, Type[Any]]:
+        return cls._registry.copy()
+
+    @classmethod
+    def create(cls, name: str, **kwargs):
+        return cls.get(name)(**kwargs)
+
+
+class RunnerRegistry(BaseRegistry):
+    _registry: Dict[str, Type[Any]] = {}
+    _registry_type = "runner"
+
+
+class ModelRegistry(BaseRegistry):
+    _registry: Dict[str, Type[Any]] = {}
+    _registry_type = "model"
+
+
+class LossRegistry(BaseRegistry):
+    _registry: Dict[str, Type[Any]] = {}
+    _registry_type = "loss"
+
+
+def register_submodules(package_name: str = "deepcoro_clip_amd", recursive: bool = True) -> None:
+    """Import every submodule so that the @register decorators run (utils/registry.py:82-94)."""
+    package = importlib.import_module(package_name)
+    for _, name, is_pkg in pkgutil.walk_packages(package.__path__, package.__name__ + "."):
+        if name.endswith(".build") or ".csrc" in name:
+            continue
+        importlib.import_module(name)

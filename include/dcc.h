@@ -1,0 +1,169 @@
+/*
+ * dcc.h — C ABI of libdcc_hip.so, the MI355X (gfx950) kernel library under the DeepCORO_CLIP
+ * video-text contrastive training path.
+ *
+ * The reference (HeartWise-AI/DeepCORO_CLIP) has no native boundary: its hot path is stock
+ * PyTorch ops called from Python.  Each entry point below replaces the ATen op(s) cited next to
+ * it; the Python modules in deepcoro_clip_amd/ (same class names and signatures as the reference's
+ * models/, utils/loss/, runners/) are the only callers, via ctypes (deepcoro_clip_amd/_lib.py parses
+ * THIS header to build the argtypes, so header and binding cannot drift).
+ *
+ * Conventions
+ *   - every function returns 0 (DCC_OK) or a negative error code; no exceptions cross the ABI
+ *   - pointers are device pointers unless noted; the library never allocates or frees caller memory
+ *   - `stream` is a hipStream_t; all work is stream-ordered and re-entrant, no global state
+ *   - dtype codes: 0 = fp32, 1 = bf16.  Accumulation / statistics are always fp32
+ *   - strides and leading dimensions are in ELEMENTS; innermost dimension is contiguous
+ *   - "accumulated into" outputs are fp32 and must be zeroed (or hold a running sum) by the caller
+ */
+#ifndef DCC_H
+#define DCC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCC_OK 0
+#define DCC_ERR_ARG (-1)
+#define DCC_ERR_LAUNCH (-2)
+#define DCC_ERR_UNSUPPORTED (-3)
+#define DCC_F32 0
+#define DCC_BF16 1
+
+/* GEMM epilogue flags */
+#define DCC_GEMM_BIAS 1
+#define DCC_GEMM_GELU 2
+#define DCC_GEMM_SAVE_PRE 4
+#define DCC_GEMM_RESID 8
+#define DCC_GEMM_DGELU 16
+#define DCC_GEMM_ACCUM 32
+#define DCC_OPT_CHUNK 4096
+
+int dcc_version(void);
+
+/* ---- MFMA GEMM (csrc/gemm.hip) --------------------------------------------------------------
+ * C[m][n] = alpha * sum_k A(m,k) B(n,k) (+bias[n]) (GELU | * GELU'(aux)) (+R[m][n])
+ * A(m,k) = a_km ? A[k*lda+m] : A[m*lda+k];  B(n,k) = b_km ? B[k*ldb+n] : B[n*ldb+k].
+ * Replaces nn.Linear forward/backward everywhere on the path: MViT qkv/project/mlp (torchvision
+ * mvit.py via models/video_encoder.py:232-253,285,376), proj heads (models/video_encoder.py:175-180,
+ * models/text_encoder.py:63-68), BERT dense layers (models/text_encoder.py:131), nn.MultiheadAttention
+ * in/out projections (models/attention_pool.py:45-50, models/video_aggregator.py:16-21), the patch-embed
+ * conv as im2col GEMM (models/video_encoder.py:237) and the similarity matmuls of the losses
+ * (utils/loss/losses.py:50, utils/loss/contrastive.py:150,263).
+ * batch > 1 walks sA/sB/sC; splitk > 1 or DCC_GEMM_ACCUM atomically accumulates into fp32 C. */
+int dcc_gemm(const void* A, const void* B, void* C, const float* bias, const void* R, void* aux, int64_t lda,
+             int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldaux, int M, int N, int K, int batch, int64_t sA,
+             int64_t sB, int64_t sC, int splitk, float alpha, int flags, int a_km, int b_km, int in_dtype,
+             int out_dtype, void* stream);
+
+/* ---- flash attention (csrc/attention.hip) ---------------------------------------------------
+ * O = softmax(scale * Qf Kf^T + kbias) V (+ Qres[q][0:DV] for q >= res_start); LSE[B,H,Nq] kept.
+ * Operands are [B, N, H, D] views; strides = {q_b,q_n,q_h, k_b,k_n,k_h, v_b,v_n,v_h, o_b,o_n,o_h}.
+ * Replaces q@k^T*scale, _add_rel_pos, softmax, attn@v and the residual-pool add of torchvision's
+ * MultiscaleAttention / the RoPE-patched forward (models/video_encoder.py:348-378), BERT SDPA
+ * (models/text_encoder.py:131) and nn.MultiheadAttention's core (models/attention_pool.py:86-91,
+ * models/video_aggregator.py:40-45).  (DQK,DV) in {(64,64),(96,96),(128,96),(160,96),(128,128)}. */
+int dcc_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, const float* kbias,
+                 const void* Qres, int res_start, const int64_t* strides, int B, int H, int Nq, int Nk, int DQK,
+                 int DV, float scale, int dtype, void* stream);
+/* strides = 21 entries: q,k,v,o,dq,dk,dv x (b,n,h).  Dv: workspace [B,H,Nq] fp32.
+ * dK/dV element type: input dtype when qsplit == 1, else fp32 pre-zeroed (atomic accumulation). */
+int dcc_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                 float* Dv, const float* kbias, const void* Qres, int res_start, void* dQ, void* dK, void* dV,
+                 const int64_t* strides, int B, int H, int Nq, int Nk, int DQK, int DV, float scale, int qsplit,
+                 int dtype, void* stream);
+
+/* ---- relative-position bias as contraction (csrc/relpos.hip) -------------------------------
+ * torchvision mvit._add_rel_pos (call site models/video_encoder.py:354-364).
+ * dims = {B,H,D,A,qt,qh,qw,kt,kh,kw,has_cls}; strides = {b,token,head} of the [B,N,H,D+A] operand. */
+int dcc_relpos_tab_fwd(void* Qf, const float* rel_h, const float* rel_w, const float* rel_t, const int* idx_h,
+                       const int* idx_w, const int* idx_t, const int* dims, const int64_t* strides, float scale,
+                       int dtype, void* stream);
+int dcc_relpos_kaug(void* Kf, const int* dims, const int64_t* strides, int dtype, void* stream);
+int dcc_relpos_tab_bwd(const void* Qf, const void* dQf, const void* dO, const int64_t* ostrides, void* dq,
+                       const float* rel_h, const float* rel_w, const float* rel_t, float* drel_h, float* drel_w,
+                       float* drel_t, const int* idx_h, const int* idx_w, const int* idx_t, const int* dims,
+                       const int64_t* strides, float scale, int dtype, void* stream);
+
+/* ---- LayerNorm (csrc/norm.hip): nn.LayerNorm in MViT blocks / Pool.norm_act / BERT / aggregator /
+ * attention pool (models/video_aggregator.py:15,24,99; models/attention_pool.py:53,94). */
+int dcc_layernorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
+                      float* mean, float* rstd, int64_t rows, int C, float eps, int dtype, void* stream);
+int dcc_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean, const float* rstd,
+                      const float* gamma, void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int C,
+                      int dtype, int grad_dtype, void* stream);
+
+/* ---- convolution-shaped ops (csrc/conv.hip) ------------------------------------------------
+ * dcc_im2col3d: operand of the conv_proj GEMM; video is NDHWC fp32 as produced by the permute+view of
+ *   models/video_encoder.py:572-574.  Column order (kt, kh, kw, cin), zero padded to Kp.
+ * dcc_pool_*: torchvision mvit.Pool (depthwise Conv3d k=3 on q/k/v heads, MaxPool3d on the skip path);
+ *   dims = {B,H,C,T,Hs,Ws,kt,kh,kw,st,sh,sw,pt,ph,pw,has_cls}; strides = {x_b,x_n,x_h,y_b,y_n,y_h};
+ *   mode 0 = depthwise conv (w [C][taps] fp32), mode 1 = max pool (argmax uint8 [B,No,H,C]). */
+int dcc_im2col3d(const float* x, void* col, int B, int T, int H, int W, int Cin, int KT, int KH, int KW, int st,
+                 int sh, int sw, int pt, int ph, int pw, int Kp, int dtype, void* stream);
+int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* argmax, const int* dims, const int64_t* strides,
+                 int mode, int dtype, void* stream);
+int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const uint8_t* argmax, const int* dims,
+                      const int64_t* strides, int mode, int dtype, int grad_dtype, void* stream);
+int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, const int* dims, const int64_t* strides,
+                          int dtype, int grad_dtype, void* stream);
+
+/* ---- streaming helpers (csrc/elementwise.hip) ---------------------------------------------- */
+int dcc_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+int dcc_cast2d(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int cols, int src_dtype,
+               int dst_dtype, void* stream);
+int dcc_axpby(void* out, float a, const void* x, float b, const void* y, int64_t n, int dtype, void* stream);
+int dcc_dgelu_mul(const void* dy, const void* pre, void* out, int64_t n, int dtype, void* stream);
+int dcc_colsum(const void* x, int64_t ldx, float* out, int64_t M, int N, int dtype, void* stream);
+int dcc_broadcast_row(const float* src, void* dst, int64_t ld, int64_t rows, int C, int dtype, void* stream);
+/* mean over tokens (models/video_encoder.py:603) */
+int dcc_token_mean(const void* in, void* out, int B, int N, int D, int backward, int dtype, void* stream);
+/* BERT embeddings (HF BertEmbeddings via models/text_encoder.py:131) */
+int dcc_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type, void* out,
+                  int64_t rows, int S, int D, int vocab, int dtype, void* stream);
+int dcc_embed_bwd(const int64_t* ids, const void* dy, float* dword, float* dpos, float* dtype_, int64_t rows, int S,
+                  int D, int vocab, int dtype, void* stream);
+/* Rope3D.forward (models/rope_3d.py:186-252); tables [N,D] fp32; strides = {x_b,x_n,x_h,y_b,y_n,y_h} */
+int dcc_rope(const void* x, void* y, const float* cos_t, const float* sin_t, int B, int N, int H, int D,
+             const int64_t* strides, int backward, int dtype, void* stream);
+/* EnhancedVideoAggregator learned-query softmax pooling (models/video_aggregator.py:131-159), fp32 */
+int dcc_qpool_fwd(const float* x, const float* q, float* out, float* w, int B, int N, int D, void* stream);
+int dcc_qpool_bwd(const float* x, const float* q, const float* w, const float* dout, float* dx, float* dq, int B,
+                  int N, int D, void* stream);
+/* torch.nan_to_num guards (runners/video_constrative_learning_runner.py:1189,1236-1238) */
+int dcc_nan_to_num(void* x, int64_t n, float nanv, float posv, float negv, int* count, int dtype, void* stream);
+int dcc_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+int dcc_scale_by_dev(float* x, int64_t n, const float* coef, void* stream);
+
+/* ---- contrastive losses (csrc/loss.hip); scal = fp32[8]
+ * {0 loss, 1 dlog_temp, 2 dbias, 3 mean diag log-softmax, 4 mean diag cosine, 5 sum ||v||, 6 sum ||t||, 7 -} */
+int dcc_l2norm_fwd(const float* x, int64_t ldx, float* y, float* norms, int R, int D, float eps, float* norm_sum,
+                   void* stream);
+int dcc_l2norm_bwd(const float* dy, const float* y, const float* norms, float* dx, int64_t lddx, int R, int D,
+                   float eps, void* stream);
+int dcc_logits_fwd(const float* sim, float* z, int B, int M, int mode, const float* log_temp, int clamp_temp,
+                   const float* bias, const float* col_margin, void* stream);
+int dcc_logits_bwd(const float* sim, const float* dz, float* dsim, int B, int M, int mode, const float* log_temp,
+                   int clamp_temp, const float* bias, float* scal, void* stream);
+int dcc_lse(const float* z, float* lse_rows, float* lse_cols, int B, int M, void* stream);
+int dcc_ce_diag(const float* z, const float* lse_r, const float* lse_c, float* dz, int B, float smooth, float* scal,
+                const float* sim, void* stream);
+int dcc_rowcol_sums(const float* w, float* rs, float* cs, int B, int M, void* stream);
+int dcc_weighted_ce(const float* z, const float* pos, const float* lse_r, const float* lse_c, const float* rs,
+                    const float* cs, float* dz, int B, int M, float eps, float* scal, void* stream);
+int dcc_bce(const float* z, const float* y, const float* pw, float pos_weight, float neg_weight, float thr,
+            float denom_host, const float* denom_dev, float* dz, int64_t n, float* scal, void* stream);
+
+/* ---- step tail (csrc/optim.hip): clip_grad_norm_ + AdamW (runner.py:1398-1421).
+ * tab = device array of DccTensorDesc {float* p,g,m,v; void* shadow; int64 n; float lr,beta1,beta2,eps,
+ * weight_decay,bc1,bc2; int flags}; work = device int2[nblocks] (tensor, chunk of DCC_OPT_CHUNK). */
+int dcc_grad_sumsq(const void* tab, const void* work, int nblocks, double* out, void* stream);
+int dcc_clip_coef(const double* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+int dcc_scale_grads(const void* tab, const void* work, int nblocks, const float* coef, void* stream);
+int dcc_adam_step(const void* tab, const void* work, int nblocks, const float* grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCC_H */

@@ -1,0 +1,110 @@
+"""HIP VideoEncoder / TextEncoder vs the CPU oracle (oracle/model.py) on the same name-seeded weights and inputs.
+
+fp32 compute: 1e-4 relative (north_star); bf16 compute: 1e-2-class tolerances, embedding argmax exact.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-6)).item()
+
+
+def _make_video(B, N, T, S, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shape = (B, N, T, S, S, 3) if N else (B, T, S, S, 3)
+    return torch.randn(shape, generator=g)
+
+
+def _grad_check(prod, orc, names_tol, default_tol):
+    """Relative Frobenius error per parameter.  Some gradients are analytically zero (a key bias / key-LayerNorm bias
+    shifts every logit of a row equally), so the denominator is floored by a fraction of the typical gradient norm."""
+    bad = []
+    op = dict(orc.named_parameters())
+    norms = sorted(float(q.grad.double().norm()) for q in op.values() if q.grad is not None)
+    floor = 1e-2 * norms[len(norms) // 2]
+    for n, p in prod.named_parameters():
+        if op[n].grad is None:
+            assert p.grad is None or p.grad.abs().max() == 0, n
+            continue
+        assert p.grad is not None, f"missing grad for {n}"
+        tol = default_tol
+        for key, t in names_tol.items():
+            if key in n:
+                tol = t
+        ref = op[n].grad.double()
+        err = ((p.grad.cpu().double() - ref).norm() / ref.norm().clamp_min(floor)).item()
+        if not err < tol:
+            bad.append((n, err))
+    assert not bad, bad[:20]
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 5e-2, 1e-1)])
+@pytest.mark.parametrize("pooling,N", [("mean", 0), ("attention", 2)])
+def test_video_encoder_vs_oracle(dtype, tol, gtol, pooling, N):
+    from deepcoro_clip_amd.video_encoder import VideoEncoder
+    from oracle.model import VideoEncoderOracle, init_by_name
+
+    T, S, B = 4, 64, 2
+    orc = init_by_name(VideoEncoderOracle(T, (S, S), token_pooling_mode=pooling)).double()
+    prod = VideoEncoder(backbone="mvit", num_frames=T, spatial_size=(S, S), pretrained=False, freeze_ratio=1.0,
+                        dropout=0.0, token_pooling_mode=pooling, attention_pool_dropout=0.0, compute_dtype=dtype)
+    prod.load_state_dict({k: v.float() for k, v in orc.state_dict().items()})
+    prod = prod.cuda().float()
+    x = _make_video(B, N, T, S)
+    ref = orc(x.double())
+    out = prod(x.cuda())
+    assert out.shape == ref.shape == (B, 512) and out.dtype == torch.float32
+    assert _rel(out.cpu(), ref) < tol, _rel(out.cpu(), ref)
+    # backward: same upstream gradient on both sides
+    g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1)).double()
+    ref.backward(g)
+    out.backward(g.float().cuda())
+    _grad_check(prod, orc, {"rel_pos": gtol * 4}, gtol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 5e-2)])
+def test_video_encoder_rope_tokens(dtype, tol):
+    from deepcoro_clip_amd.video_encoder import VideoEncoder
+    from oracle.model import VideoEncoderOracle, init_by_name
+
+    T, S, B, N = 4, 64, 1, 2
+    orc = init_by_name(VideoEncoderOracle(T, (S, S), use_rope=True, aggregate_videos_tokens=False)).double()
+    prod = VideoEncoder(num_frames=T, spatial_size=(S, S), pretrained=False, freeze_ratio=1.0, dropout=0.0, use_rope=True,
+                        aggregate_videos_tokens=False, per_video_pool=False, compute_dtype=dtype)
+    prod.load_state_dict({k: v.float() for k, v in orc.state_dict().items()})
+    prod = prod.cuda()
+    x = _make_video(B, N, T, S, seed=3)
+    ref = orc(x.double())
+    out = prod(x.cuda())
+    assert out.shape == ref.shape  # [B, N*L, 512] patch tokens (tests/test_video_encoder_tokens.py:37-54)
+    assert _rel(out.float().cpu(), ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 5e-2, 1e-1)])
+def test_text_encoder_vs_oracle(dtype, tol, gtol):
+    from deepcoro_clip_amd.text_encoder import TextEncoder
+    from oracle.model import TextEncoderOracle, init_by_name
+
+    small = dict(vocab=1000, hidden=768, layers=2, heads=12, ffn=3072, max_pos=64)
+    orc = init_by_name(TextEncoderOracle(**small)).double()
+    prod = TextEncoder(dropout=0.0, freeze_ratio=0.0, compute_dtype=dtype,
+                       bert_config=dict(vocab_size=1000, num_hidden_layers=2, max_position_embeddings=64,
+                                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+    prod.load_state_dict({k: v.float() for k, v in orc.state_dict().items()})
+    prod = prod.cuda()
+    g = torch.Generator().manual_seed(2)
+    B, S = 3, 32
+    ids = torch.randint(0, 1000, (B, S), generator=g)
+    mask = torch.ones(B, S, dtype=torch.int64)
+    mask[1, 20:] = 0  # right padding
+    ref = orc(ids, mask)
+    out = prod(ids.cuda(), mask.cuda())
+    assert out.shape == (B, 512)
+    assert _rel(out.float().cpu(), ref) < tol
+    gg = torch.randn(ref.shape, generator=g).double()
+    ref.backward(gg)
+    out.backward(gg.to(out.dtype).cuda())
+    _grad_check(prod, orc, {}, gtol)
