@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench.py — video-text clip-pairs/sec of the contrastive training step on N MI355X GPUs of one node.
+
+A "step" = one `_train_step` (VideoEncoder fwd/bwd + TextEncoder fwd/bwd + InfoNCE loss + gradient reduction +
+clip + AdamW) on one synthetic batch that is already resident in HBM.  One process per GPU (torch.distributed /
+RCCL); N=1 runs BASELINE.json configs[1]: single-video CLIP, 16 x 224 x 224, MViT-v2-S + BERT-base, bf16, B=24/GPU
+(config/clip/base_config.yaml:23).  Weak scaling: per-GPU batch fixed, `value` = global pairs per second.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with:
+  roofline     — the dominant kernel family (bf16 MFMA GEMM) timed per launch with HIP events on the launch stream
+                 in an instrumented pass of the same K steps right after the timed region (events off during it)
+  cpu_baseline — the CPU oracle (oracle/, a port) doing the same training step on a bounded sample, rank 0, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+
+class _Cfg:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def build_job(args, device, world, rank):
+    from deepcoro_clip_amd.ddp import HipDDP
+    from deepcoro_clip_amd.losses import Loss
+    from deepcoro_clip_amd.optim import HipAdamW
+    from deepcoro_clip_amd.registry import LossRegistry, register_submodules
+    from deepcoro_clip_amd.runner import VideoContrastiveLearningRunner
+    from deepcoro_clip_amd.text_encoder import TextEncoder
+    from deepcoro_clip_amd.video_encoder import VideoEncoder
+
+    register_submodules("deepcoro_clip_amd")
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)  # same random-init weights on every rank
+    ve = VideoEncoder(backbone="mvit", num_frames=args.frames, spatial_size=(args.size, args.size), pretrained=False,
+                      freeze_ratio=1.0, dropout=0.0, token_pooling_mode=args.pooling, attention_pool_dropout=0.0,
+                      compute_dtype=dtype).to(device)
+    te = TextEncoder(dropout=0.0, freeze_ratio=0.0, compute_dtype=dtype,
+                     bert_config=dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).to(device)
+    ve.train()
+    te.train()
+    vew, tew = ve, te
+    if world > 1:
+        vew, tew = HipDDP(ve, device_ids=[device.index]), HipDDP(te, device_ids=[device.index])
+    log_temp = torch.nn.Parameter(torch.log(torch.tensor([0.07], device=device)))
+    # param groups of projects/contrastive_pretraining_project.py:128-179
+    groups = [{"params": list(ve.model.parameters()), "lr": 1e-4, "name": "video_backbone", "weight_decay": 1e-6}]
+    if ve.attention_pool is not None:
+        groups.append({"params": list(ve.attention_pool.parameters()), "lr": 2e-4, "name": "video_attention_pool", "weight_decay": 1e-6})
+    groups += [{"params": list(ve.aggregator.parameters()), "lr": 2e-4, "name": "video_aggregator", "weight_decay": 1e-6},
+               {"params": list(te.parameters()), "lr": 2e-5, "name": "text_encoder", "weight_decay": 1e-6},
+               {"params": [log_temp], "lr": 1e-4, "name": "temperature"}]
+    opt = HipAdamW(groups, lr=1e-4)
+    loss_name = "contrastive_ddp" if world > 1 else "contrastive"
+    cfg = _Cfg(recall_k=[1, 5], ndcg_k=[5], device=device, world_size=world, gradient_accumulation_steps=1,
+               max_grad_norm=5.0, is_ref_device=rank == 0, loss_name=loss_name, scheduler_name="", temperature=0.07)
+    runner = VideoContrastiveLearningRunner(config=cfg, wandb_wrapper=None, train_loader=None, val_loader=None,
+                                            video_encoder=vew, text_encoder=tew, optimizer=opt, scaler=None,
+                                            log_temp=log_temp, lr_scheduler=None,
+                                            loss_fn=Loss(loss_type=LossRegistry.get(loss_name)()), output_dir=None)
+    g = torch.Generator().manual_seed(1234 + rank)
+    shape = (args.batch, args.videos, args.frames, args.size, args.size, 3) if args.videos > 1 else \
+        (args.batch, args.frames, args.size, args.size, 3)
+    videos = torch.randn(shape, generator=g).to(device)
+    ids = torch.randint(0, 30522, (args.batch, args.seq), generator=g).to(device)
+    mask = torch.ones(args.batch, args.seq, dtype=torch.int64, device=device)
+    return runner, dict(videos=videos, input_ids=ids, attention_mask=mask)
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a port of the reference algorithm) timed on this host: fwd + bwd + AdamW, bounded sample."""
+    from oracle.losses import contrastive_loss
+    from oracle.model import TextEncoderOracle, VideoEncoderOracle, init_by_name
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    B = 2
+    vo = init_by_name(VideoEncoderOracle(args.frames, (args.size, args.size)))
+    to = init_by_name(TextEncoderOracle())
+    lt = torch.nn.Parameter(torch.log(torch.tensor([0.07])))
+    opt = torch.optim.AdamW(list(vo.parameters()) + list(to.parameters()) + [lt], lr=1e-4)
+    g = torch.Generator().manual_seed(1234)
+    videos = torch.randn(B, args.frames, args.size, args.size, 3, generator=g)
+    ids = torch.randint(0, 30522, (B, args.seq), generator=g)
+    mask = torch.ones(B, args.seq, dtype=torch.int64)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = contrastive_loss(vo(videos), to(ids, mask), lt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(vo.parameters()) + list(to.parameters()), 5.0)
+        opt.step()
+
+    step()  # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < 12.0 and n < 8):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": B * n / dt, "unit": "clip-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fp32 training steps of B={B} clips {args.frames}x{args.size}x{args.size} + {args.seq}-token texts, "
+                      f"oracle/ (plain PyTorch CPU), torch.set_num_threads({cores})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=24, help="per-GPU batch (studies)")
+    ap.add_argument("--videos", type=int, default=1, help="videos per study")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--seq", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--pooling", default="mean", choices=["mean", "attention"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from deepcoro_clip_amd import kernels as K
+
+    runner, batch = build_job(args, device, world, rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss0 = None
+    for _ in range(args.warmup):
+        m, _ = runner._train_step(**batch)
+        loss0 = m["loss"] if loss0 is None else loss0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m, _ = runner._train_step(**batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    pairs_per_step = args.batch * world  # one text per study; N videos per study counted as one pair-study
+    clips_per_step = args.batch * args.videos * world
+    value = clips_per_step * args.steps / dt
+
+    roofline = None
+    if not args.no_roofline:
+        K.TIMER = K.KernelTimer()
+        for _ in range(args.steps):
+            runner._train_step(**batch)
+        summ = K.TIMER.summary()
+        K.TIMER = None
+        fam = "gemm_bf16" if args.dtype == "bf16" else "gemm_f32"
+        if fam in summ and summ[fam]["ms"] > 0:
+            s = summ[fam]
+            achieved = s["units"] / (s["ms"] * 1e-3) / 1e12
+            peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+            roofline = {"bound": "mfma", "kernel": "gemm_kernel<" + args.dtype + ">", "achieved": round(achieved, 2),
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                        "launches_per_step": s["launches"] // args.steps,
+                        "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 2),
+                        "gflop_per_step": round(s["units"] / args.steps / 1e9, 1),
+                        "ms_per_step_in_kernel": round(s["ms"] / args.steps, 2),
+                        "other_families_ms_per_step": {k: round(v["ms"] / args.steps, 2) for k, v in summ.items() if k != fam}}
+    barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        out = {
+            "metric": "video-text clip-pairs/sec (whole node), contrastive training step",
+            "value": round(value, 3), "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"single-video CLIP step: MViT-v2-S {args.frames}x{args.size}x{args.size} + BERT-base "
+                                   f"S={args.seq}, InfoNCE, AdamW, B={args.batch}/GPU x N={args.videos} videos/study"
+                       if args.videos == 1 else
+                       f"multi-video CLIP step: MViT-v2-S {args.frames}x{args.size}x{args.size} x N={args.videos} + "
+                       f"{args.pooling} pooling + aggregator, BERT-base S={args.seq}, B={args.batch}/GPU",
+                       "global_batch": pairs_per_step, "clips_per_step": clips_per_step, "seq_len": args.seq,
+                       "parallelism": f"dp{world}", "loss_first": loss0, "loss_last": m["loss"]},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,7 +13,6 @@ import torch
 from . import kernels as K
 
 # ------------------------------------------------------------------------------ weight shadows
-_WCACHE: dict = {}
 _WEPOCH = 0
 
 
@@ -21,21 +20,29 @@ def invalidate_weight_cache() -> None:
     """Call after parameters were updated through raw pointers (our fused optimizer)."""
     global _WEPOCH
     _WEPOCH += 1
-    _WCACHE.clear()
 
 
 def wcast(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """fp32 parameter -> contiguous tensor in the compute dtype (cached per parameter version)."""
+    """fp32 parameter (or a slice view of one) -> contiguous tensor in the compute dtype.
+
+    The shadow is cached ON the owning parameter object (never keyed by address: freed parameters' addresses are
+    reused by the allocator) and is valid for one (autograd version, optimizer epoch) pair."""
     wd = w.detach()
     if dtype == torch.float32:
         return wd if wd.is_contiguous() else wd.contiguous()
-    key = (wd.data_ptr(), tuple(wd.shape), dtype)
-    hit = _WCACHE.get(key)
-    if hit is not None and hit[0] == w._version:
+    owner = w._base if w._base is not None else w
+    cache = owner.__dict__.get("_dcc_shadows")
+    if cache is None:
+        cache = {}
+        owner.__dict__["_dcc_shadows"] = cache
+    key = (w.storage_offset(), tuple(w.shape), tuple(w.stride()), dtype)
+    stamp = (owner._version, _WEPOCH, owner.data_ptr())
+    hit = cache.get(key)
+    if hit is not None and hit[0] == stamp:
         return hit[1]
     src = wd if wd.is_contiguous() else wd.contiguous()
     t = K.cast(src, dtype)
-    _WCACHE[key] = (w._version, t)
+    cache[key] = (stamp, t)
     return t
 
 

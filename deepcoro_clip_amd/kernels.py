@@ -15,6 +15,59 @@ from . import _lib as L
 GEMM_BIAS, GEMM_GELU, GEMM_SAVE_PRE, GEMM_RESID, GEMM_DGELU, GEMM_ACCUM = 1, 2, 4, 8, 16, 32
 
 
+class KernelTimer:
+    """HIP-event timing of individual kernel families on the launch stream (bench.py roofline leg).
+
+    Events are recorded on torch's current stream, which is the stream every dcc_* launch uses."""
+
+    def __init__(self):
+        self.records: dict[str, list] = {}
+
+    def time(self, family: str, units: float):
+        return _TimerCtx(self, family, units)
+
+    def summary(self) -> dict:
+        torch.cuda.synchronize()
+        out = {}
+        for fam, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            units = sum(u for _, _, u in recs)
+            out[fam] = {"launches": len(recs), "ms": ms, "units": units}
+        return out
+
+
+class _TimerCtx:
+    def __init__(self, timer, family, units):
+        self.t, self.f, self.u = timer, family, units
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.t.records.setdefault(self.f, []).append((self.a, self.b, self.u))
+
+
+TIMER: KernelTimer | None = None  # set by bench.py for the instrumented pass only
+
+
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def _timed(family: str, units: float):
+    return TIMER.time(family, units) if TIMER is not None else _NOCTX
+
+
 def _i64(vals):
     return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
 
@@ -62,9 +115,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
         flags |= GEMM_RESID
     if accumulate:
         flags |= GEMM_ACCUM
-    L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), L.ptr(resid), L.ptr(aux), a.stride(0), b.stride(0),
-           out.stride(0), resid.stride(0) if resid is not None else 0, aux.stride(0) if aux is not None else 0, M, N, K,
-           1, 0, 0, 0, splitk, float(alpha), flags, int(a_km), int(b_km), L.dt(a), L.dt(out), L.stream())
+    with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K):
+        L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), L.ptr(resid), L.ptr(aux), a.stride(0),
+               b.stride(0), out.stride(0), resid.stride(0) if resid is not None else 0,
+               aux.stride(0) if aux is not None else 0, M, N, K, 1, 0, 0, 0, splitk, float(alpha), flags, int(a_km),
+               int(b_km), L.dt(a), L.dt(out), L.stream())
     return out
 
 
@@ -73,8 +128,9 @@ def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=N
     """Raw batched form (base tensors + explicit strides); `a`/`b`/`out` only provide base pointers and dtypes."""
     L.require_cuda(a, b, out, bias)
     flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_ACCUM if accumulate else 0)
-    L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), None, None, lda, ldb, ldc, 0, 0, M, N, K, batch, sA,
-           sB, sC, splitk, float(alpha), flags, int(a_km), int(b_km), L.dt(a), L.dt(out), L.stream())
+    with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * batch):
+        L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), None, None, lda, ldb, ldc, 0, 0, M, N, K, batch,
+               sA, sB, sC, splitk, float(alpha), flags, int(a_km), int(b_km), L.dt(a), L.dt(out), L.stream())
     return out
 
 
@@ -104,8 +160,10 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: float,
     if kbias is not None:
         assert kbias.shape == (B, Nk) and kbias.dtype == torch.float32 and kbias.is_contiguous()
     st = _i64(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o))
-    L.call("dcc_attn_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(kbias),
-           L.ptr(q) if residual else None, int(res_start), st, B, H, Nq, Nk, DQK, DV, float(scale), L.dt(q), L.stream())
+    with _timed("attn_fwd", 2.0 * B * H * Nq * Nk * (DQK + DV)):
+        L.call("dcc_attn_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(kbias),
+               L.ptr(q) if residual else None, int(res_start), st, B, H, Nq, Nk, DQK, DV, float(scale), L.dt(q),
+               L.stream())
     return o, lse
 
 
@@ -128,9 +186,11 @@ def attn_bwd(q, k, v, o, do, lse, *, scale: float, kbias=None, residual: bool = 
     dv = alloc((B, Nk, H, DV), device=q.device, dtype=kv_dtype)
     dvec = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
     st = _i64(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o) + _strides3(dq) + _strides3(dk) + _strides3(dv))
-    L.call("dcc_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(dvec), L.ptr(kbias),
-           L.ptr(q) if residual else None, int(res_start), L.ptr(dq), L.ptr(dk), L.ptr(dv), st, B, H, Nq, Nk, DQK, DV,
-           float(scale), int(qsplit), L.dt(q), L.stream())
+    # dQ kernel: S, dP, dQ products; dK/dV kernel: S, dP, dV, dK products
+    with _timed("attn_bwd", 2.0 * B * H * Nq * Nk * (3 * DQK + 4 * DV)):
+        L.call("dcc_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(dvec),
+               L.ptr(kbias), L.ptr(q) if residual else None, int(res_start), L.ptr(dq), L.ptr(dk), L.ptr(dv), st, B, H,
+               Nq, Nk, DQK, DV, float(scale), int(qsplit), L.dt(q), L.stream())
     return dq, dk, dv
 
 

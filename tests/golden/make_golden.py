@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Generate the golden vectors that pin oracle/ to the REFERENCE's own arithmetic.
+
+Runs only in the build container (needs /root/reference, read-only): imports the reference's importable hot-path
+modules — utils/loss/{losses,contrastive,weighted_siglip}.py, utils/retrieval_metrics.py and, by file
+path, models/{rope_3d,attention_pool,video_aggregator}.py — plus HF `BertModel(BertConfig(...))` (the arithmetic
+behind models/text_encoder.py:52,131), evaluates them on seeded inputs and stores inputs + outputs as small .npz
+fixtures.  Nothing of the reference's source travels: fixtures are plain arrays.
+
+    python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+ROOT = os.path.dirname(os.path.dirname(OUT))
+sys.path.insert(1, ROOT)
+
+
+def load_by_path(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def init_by_name(module, seed=0):
+    # must stay identical to oracle.model.init_by_name
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + seed) & 0x7FFFFFFF)
+            r = torch.randn(p.shape, generator=g)
+            lname = name.lower()
+            is_norm = p.dim() == 1 and any(t in lname for t in ("norm", "final_ln"))
+            if is_norm and name.endswith("weight"):
+                p.copy_(1.0 + 0.1 * r)
+            elif p.dim() == 1:
+                p.copy_(0.02 * r)
+            elif "conv_proj" in name or ".pool." in name or "rel_pos" in name:
+                p.copy_(0.1 * r)
+            else:
+                p.copy_(0.02 * r)
+    return module
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def losses():
+    from utils.loss import contrastive as C
+    from utils.loss import losses as Ls
+    from utils.loss.weighted_siglip import WeightedSigLIPLoss
+
+    out = {}
+    for B in (8, 24):
+        g = torch.Generator().manual_seed(0)
+        v = torch.randn(B, 512, generator=g).requires_grad_(True)
+        t = torch.randn(B, 512, generator=g).requires_grad_(True)
+        lt = torch.log(torch.tensor(0.07)).requires_grad_(True)
+        out[f"v{B}"], out[f"t{B}"] = np_(v), np_(t)
+        for name, mod in (("contrastive", Ls.ContrastiveLoss()), ("clip", C.CLIPLoss()), ("clip_ls", C.CLIPLoss(label_smoothing=0.1)),
+                          ("siglip_gated", Ls.SiglipLoss()), ("siglip_bce", C.SigLIPLoss())):
+            for x in (v, t, lt):
+                x.grad = None
+            params = list(mod.parameters())
+            loss = mod(v, t, lt)
+            loss.backward()
+            out[f"{name}{B}_loss"] = np_(loss)
+            out[f"{name}{B}_dv"], out[f"{name}{B}_dt"], out[f"{name}{B}_dlt"] = np_(v.grad), np_(t.grad), np_(lt.grad)
+            if params:
+                out[f"{name}{B}_dbias"] = np_(params[0].grad)
+    # multi-positive: 8 videos x 13 texts
+    g = torch.Generator().manual_seed(7)
+    v = torch.randn(8, 512, generator=g).requires_grad_(True)
+    t = torch.randn(13, 512, generator=g).requires_grad_(True)
+    lt = torch.log(torch.tensor(0.07)).requires_grad_(True)
+    mask = torch.zeros(8, 13)
+    for i in range(8):
+        for j in torch.randperm(13, generator=g)[: 1 + i % 3].tolist():
+            mask[i, j] = 1.0
+    w = mask * (1.0 + 9.0 * torch.rand(8, 13, generator=g))
+    out.update(mp_v=np_(v), mp_t=np_(t), mp_mask=np_(mask), mp_w=np_(w))
+    # contrastive.SigLIPLoss with pos_mask / pos_weights
+    mod = C.SigLIPLoss()
+    loss = mod(v, t, lt, pos_mask=mask, pos_weights=w)
+    loss.backward()
+    out.update(mp_bce_loss=np_(loss), mp_bce_dv=np_(v.grad), mp_bce_dt=np_(t.grad), mp_bce_dlt=np_(lt.grad),
+               mp_bce_dbias=np_(mod.bias.grad))
+    # runner inline branch (runners/video_constrative_learning_runner.py:1256-1296) evaluated with the reference's
+    # own WeightedSigLIPLoss / F.binary_cross_entropy_with_logits on the reference's gated logits
+    import torch.nn.functional as F
+
+    for x in (v, t, lt):
+        x.grad = None
+    sim = F.normalize(v, dim=1) @ F.normalize(t, dim=1).t()
+    logits = sim * torch.sigmoid(sim) / torch.exp(lt.float())
+    loss = WeightedSigLIPLoss()(logits=logits, positive_weights=mask * w)
+    loss.backward()
+    out.update(mp_wce_loss=np_(loss), mp_wce_dv=np_(v.grad), mp_wce_dt=np_(t.grad), mp_wce_dlt=np_(lt.grad))
+    for x in (v, t, lt):
+        x.grad = None
+    sim = F.normalize(v, dim=1) @ F.normalize(t, dim=1).t()
+    logits = sim * torch.sigmoid(sim) / torch.exp(lt.float())
+    wm = torch.where(mask > 0, w, torch.full_like(mask, 1.0))
+    loss = F.binary_cross_entropy_with_logits(logits, mask, weight=wm, reduction="sum") / max(1.0, float(mask.sum()))
+    loss.backward()
+    out.update(mp_rbce_loss=np_(loss), mp_rbce_dv=np_(v.grad), mp_rbce_dt=np_(t.grad), mp_rbce_dlt=np_(lt.grad))
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
+
+
+def rope():
+    R = load_by_path("ref_rope_3d", "models/rope_3d.py")
+    out = {}
+    g = torch.Generator().manual_seed(3)
+    m = R.Rope3D(embed_dim=4 * 96, num_heads=4).eval()
+    q = torch.randn(2, 4, 393, 96, generator=g)
+    k = torch.randn(2, 4, 393, 96, generator=g)
+    qr, kr = m(q, k, 8, 7, 7, n_special=1)
+    tok = torch.tensor(list(range(0, 60)) + list(range(200, 212)) + list(range(385, 393)))
+    out.update(tok=np_(tok), q=np_(q[:, :, tok]), k=np_(k[:, :, tok]), q_rot=np_(qr[:, :, tok]), k_rot=np_(kr[:, :, tok]))
+    # asymmetric grids as in the patched attention (q grid 8x14x14, k grid 8x7x7), small batch
+    q2 = torch.randn(1, 4, 1 + 8 * 14 * 14, 96, generator=g)
+    k2 = torch.randn(1, 4, 1 + 8 * 7 * 7, 96, generator=g)
+    q2r, _ = m(q2, q2, 8, 14, 14, n_special=1)
+    _, k2r = m(k2, k2, 8, 7, 7, n_special=1)
+    sel = torch.tensor([0, 1, 2, 15, 197, 198, 1568])
+    out.update(q2_sel=np_(q2[:, :, sel]), q2_rot_sel=np_(q2r[:, :, sel]), sel=np_(sel), k2_sel=np_(k2[:, :, :8]),
+               k2_rot_sel=np_(k2r[:, :, :8]))
+    sin, cos = m._get_cached_freqs(8, 7, 7, torch.device("cpu"), torch.float32, 1)
+    out.update(sin=np_(sin), cos=np_(cos))
+    np.savez_compressed(os.path.join(OUT, "rope.npz"), **out)
+
+
+def pools():
+    AP = load_by_path("ref_attention_pool", "models/attention_pool.py")
+    AG = load_by_path("ref_video_aggregator", "models/video_aggregator.py")
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    ap = init_by_name(AP.AttentionPool(512, num_heads=8, dropout=0.0)).eval()
+    x = torch.randn(2, 50, 512, generator=g)
+    out.update(ap_x=np_(x), ap_y=np_(ap(x)))
+    ag = init_by_name(AG.EnhancedVideoAggregator(512, num_heads=4, dropout=0.0, aggregator_depth=2)).eval()
+    for n in (1, 4, 8):
+        xn = torch.randn(2, n, 512, generator=g)
+        out[f"ag_x{n}"], out[f"ag_y{n}"] = np_(xn), np_(ag(xn))
+    np.savez_compressed(os.path.join(OUT, "pools.npz"), **out)
+
+
+def bert():
+    from transformers import BertConfig, BertModel
+
+    cfg = BertConfig(vocab_size=1000, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072,
+                     max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = init_by_name(BertModel(cfg, add_pooling_layer=False)).eval()
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, 1000, (3, 32), generator=g)
+    mask = torch.ones(3, 32, dtype=torch.int64)
+    mask[1, 20:] = 0
+    with torch.no_grad():
+        h = m(input_ids=ids, attention_mask=mask).last_hidden_state
+    np.savez_compressed(os.path.join(OUT, "bert.npz"), ids=np_(ids), mask=np_(mask), cls=np_(h[:, 0]), tok5=np_(h[:, 5]),
+                        keys=np.array(sorted(m.state_dict().keys())))
+
+
+def retrieval():
+    import utils.retrieval_metrics as RM
+
+    out = {}
+    torch.manual_seed(42)
+    sim = torch.randn(100, 100)
+    gt = torch.arange(100)
+    out["sim"] = np_(sim)
+    rec = RM.compute_recall_at_k(sim, gt, [1, 5, 10])
+    out.update(recall=np.array([rec["Recall@1"], rec["Recall@5"], rec["Recall@10"]]), mrr=np.array(RM.compute_mrr(sim, gt)["MRR_V2T"]),
+               map=np.array(RM.compute_map(sim, gt)), median=np.array(RM.compute_median_rank(sim, gt)),
+               ndcg=np.array([RM.compute_ndcg_at_k(sim, gt, [5, 10])[k] for k in ("NDCG@5_V2T", "NDCG@10_V2T")]))
+    # multi-label, non-square (10 queries x 5 candidates)
+    sim2 = torch.randn(10, 5)
+    gt2 = [[0, 2], [1], [4, 3], [], [2], [0], [1, 4], [3], [2, 0], [4]]
+    rec2 = RM.compute_recall_at_k(sim2, gt2, [1, 3, 10])
+    out.update(sim2=np_(sim2), gt2=np.array([g + [-1] * (2 - len(g)) for g in gt2]),
+               recall2=np.array([rec2["Recall@1"], rec2["Recall@3"], rec2["Recall@10"]]),
+               mrr2=np.array(RM.compute_mrr(sim2, gt2)["MRR_V2T"]), map2=np.array(RM.compute_map(sim2, gt2)),
+               median2=np.array(RM.compute_median_rank(sim2, gt2)),
+               ndcg2=np.array([RM.compute_ndcg_at_k(sim2, gt2, [3])["NDCG@3_V2T"]]))
+    v = torch.randn(16, 512)
+    t = torch.randn(16, 512)
+    out.update(ev=np_(v), et=np_(t), norms=np.array(list(RM.compute_embedding_norms(v, t).values())),
+               align=np.array(RM.compute_alignment_score(v, t)))
+    np.savez_compressed(os.path.join(OUT, "retrieval.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    for fn in (losses, rope, pools, bert, retrieval):
+        fn()
+        print("wrote", fn.__name__)

@@ -41,7 +41,7 @@ def _grad_check(prod, orc, names_tol, default_tol):
     assert not bad, bad[:20]
 
 
-@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 5e-2, 1e-1)])
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 5e-2, 2e-1)])
 @pytest.mark.parametrize("pooling,N", [("mean", 0), ("attention", 2)])
 def test_video_encoder_vs_oracle(dtype, tol, gtol, pooling, N):
     from deepcoro_clip_amd.video_encoder import VideoEncoder
@@ -83,7 +83,7 @@ def test_video_encoder_rope_tokens(dtype, tol):
     assert _rel(out.float().cpu(), ref) < tol
 
 
-@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 5e-2, 1e-1)])
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 5e-2, 2e-1)])
 def test_text_encoder_vs_oracle(dtype, tol, gtol):
     from deepcoro_clip_amd.text_encoder import TextEncoder
     from oracle.model import TextEncoderOracle, init_by_name

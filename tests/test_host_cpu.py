@@ -1,0 +1,145 @@
+"""CPU: C-ABI library loads and exports every symbol of include/dcc.h; host logic (registry, geometry, freezing,
+state_dict names, optimizer adoption, fail-loud without GPU)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    from deepcoro_clip_amd import _lib as L
+
+    text = open(os.path.join(ROOT, "include", "dcc.h")).read()
+    declared = set(re.findall(r"\bint\s+(dcc_\w+)\s*\(", text))
+    assert len(declared) >= 40 and declared == set(L.SIGNATURES)
+    handle = L.lib()
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert handle.dcc_version() == 0
+
+
+def test_product_fails_loudly_on_cpu_tensors():
+    from deepcoro_clip_amd import _lib as L
+    from deepcoro_clip_amd import kernels as K
+    from deepcoro_clip_amd.losses import ContrastiveLoss
+
+    with pytest.raises(L.DccError):
+        K.gemm(torch.randn(8, 8), torch.randn(8, 8))
+    with pytest.raises(L.DccError):
+        ContrastiveLoss()(torch.randn(4, 512), torch.randn(4, 512), torch.log(torch.tensor(0.07)))
+
+
+def test_no_oracle_import_in_product():
+    pkg = os.path.join(ROOT, "deepcoro_clip_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_registry_names():
+    from deepcoro_clip_amd.registry import LossRegistry, ModelRegistry, RunnerRegistry, register_submodules
+
+    register_submodules("deepcoro_clip_amd")
+    for n in ("contrastive", "contrastive_ddp", "clip", "siglip", "siglip_ddp", "InfoNCE", "siglip_pairwise", "siglip2_bce",
+              "siglip2_bce_ddp", "siglip2_multi_positive"):
+        assert LossRegistry.get(n) is not None
+        LossRegistry.get(n)()  # no-arg constructible (projects/contrastive_pretraining_project.py:204-206)
+    assert ModelRegistry.get("video_encoder").__name__ == "VideoEncoder"
+    assert ModelRegistry.get("text_encoder").__name__ == "TextEncoder"
+    assert RunnerRegistry.get("DeepCORO_clip") is RunnerRegistry.get("DeepCORO_clip_test")
+    with pytest.raises(ValueError):
+        LossRegistry.get("nope")
+
+
+def test_block_plan_geometry():
+    from deepcoro_clip_amd.mvit import block_plan
+
+    plan = block_plan(16, (224, 224))
+    assert plan[0]["thw"] == (8, 56, 56) and plan[0]["k_thw"] == (8, 7, 7) and plan[0]["rel_sp"] == 111 and plan[0]["rel_t"] == 15
+    assert [p["q_thw"] for p in plan][-3:] == [(8, 14, 14), (8, 7, 7), (8, 7, 7)]
+    tokens = [1 + p["thw"][0] * p["thw"][1] * p["thw"][2] for p in plan]
+    assert tokens[0] == 25089 and tokens[2] == 6273 and tokens[4] == 1569 and tokens[15] == 393
+    assert block_plan(4, (112, 112))[15]["q_thw"] == (2, 4, 4)
+
+
+def test_video_encoder_contract_and_freezing():
+    from deepcoro_clip_amd.video_encoder import VideoEncoder
+    from oracle.model import VideoEncoderOracle
+
+    with pytest.raises(ValueError):
+        VideoEncoder(backbone="resnet", pretrained=False)
+    with pytest.raises(ValueError):
+        VideoEncoder(pretrained=False, output_dim=510, num_heads=4, num_frames=4, spatial_size=(64, 64))
+    v = VideoEncoder(pretrained=False, num_frames=4, spatial_size=(64, 64), freeze_ratio=0.25, token_pooling_mode="attention")
+    names = [n for n, _ in v.model.named_parameters()]
+    flags = [p.requires_grad for _, p in v.model.named_parameters()]
+    k = int(0.25 * len(names))
+    assert flags == [False] * (len(names) - k) + [True] * k  # trainable fraction counted from the top (quirk 1)
+    v.update_freeze_ratio(1.0)
+    assert all(p.requires_grad for p in v.model.parameters())
+    assert v.embedding_dim == 512 and v.attention_pool is not None and hasattr(v, "aggregator") and hasattr(v, "proj")
+    ref_keys = list(VideoEncoderOracle(4, (64, 64), token_pooling_mode="attention").state_dict().keys())
+    assert list(v.state_dict().keys()) == ref_keys
+    with pytest.raises(Exception):  # CPU tensors are refused: no fallback
+        v(torch.randn(1, 4, 64, 64, 3))
+
+
+def test_text_encoder_contract():
+    from deepcoro_clip_amd.text_encoder import TextEncoder
+
+    t = TextEncoder(freeze_ratio=0.5, bert_config=dict(num_hidden_layers=2, vocab_size=100))
+    ps = list(t.bert.named_parameters())
+    k = int(0.5 * len(ps))
+    assert [p.requires_grad for _, p in ps] == [False] * (len(ps) - k) + [True] * k
+    t.update_freeze_ratio(0.0)
+    assert all(p.requires_grad for p in t.bert.parameters())
+    assert any(n == "bert.encoder.layer.0.attention.self.query.weight" for n, _ in t.named_parameters())
+    full = TextEncoder(freeze_ratio=0.0)
+    assert sum(p.numel() for p in full.bert.parameters()) == 108_891_648 and len(list(full.bert.parameters())) == 197
+
+
+def test_relpos_index_matches_oracle():
+    from deepcoro_clip_amd.functional import relpos_index
+
+    for q, k in ((56, 7), (28, 14), (7, 7), (14, 7), (8, 8), (2, 2)):
+        qr, kr = max(k / q, 1.0), max(q / k, 1.0)
+        ref = (torch.arange(q)[:, None] * qr - (torch.arange(k)[None, :] + (1.0 - k)) * kr).long()
+        assert torch.equal(relpos_index(q, k).long(), ref)
+        assert ref.min() >= 0 and ref.max() <= 2 * max(q, k) - 2
+
+
+def test_runner_validates_config():
+    from deepcoro_clip_amd.runner import VideoContrastiveLearningRunner
+
+    class C:
+        recall_k, ndcg_k, device, world_size, temperature = 5, [5], "cpu", 1, 0.07
+
+    with pytest.raises(ValueError):
+        VideoContrastiveLearningRunner(config=C(), log_temp=torch.tensor(0.0))
+    r = VideoContrastiveLearningRunner.__new__(VideoContrastiveLearningRunner)
+    with pytest.raises(NotImplementedError):
+        r.validate()
+
+
+def test_retrieval_metrics_host_part_matches_golden():
+    import numpy as np
+
+    from deepcoro_clip_amd import retrieval_metrics as RM
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "retrieval.npz"))
+    sim, gt = torch.from_numpy(g["sim"]), torch.arange(100)
+    rec = RM.compute_recall_at_k(sim, gt, [1, 5, 10])
+    assert [rec["Recall@1"], rec["Recall@5"], rec["Recall@10"]] == pytest.approx(list(g["recall"]))
+    assert RM.compute_mrr(sim, gt)["MRR_V2T"] == pytest.approx(float(g["mrr"]), abs=1e-9)
+    assert RM.compute_map(sim, gt) == pytest.approx(float(g["map"]), abs=1e-7)
+    assert RM.compute_median_rank(sim, gt) == int(g["median"])
+    assert RM.compute_ndcg_at_k(sim, gt, [5, 10])["NDCG@5_V2T"] == pytest.approx(float(g["ndcg"][0]), abs=1e-7)
+    gt2 = [[int(x) for x in row if x >= 0] for row in g["gt2"]]
+    sim2 = torch.from_numpy(g["sim2"])
+    assert RM.compute_median_rank(sim2, gt2) == int(g["median2"])
+    assert RM.compute_map(sim2, gt2) == pytest.approx(float(g["map2"]), abs=1e-7)
+    assert RM.compute_recall_at_k(sim2, gt2, [10])["Recall@10"] == pytest.approx(float(g["recall2"][2]))

@@ -1,0 +1,183 @@
+"""CPU: the oracle (oracle/) against golden vectors produced by the REFERENCE's own modules
+(tests/golden/make_golden.py) and against the reference's known-answer tests (tests/test_retrieval_metrics.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("B", [8, 24])
+@pytest.mark.parametrize("name,kw", [("contrastive", {}), ("clip", {"clamp_temp": True}),
+                                     ("clip_ls", {"clamp_temp": True, "label_smoothing": 0.1}),
+                                     ("siglip_gated", {"gated": True})])
+def test_ce_losses_match_reference(B, name, kw):
+    from oracle.losses import contrastive_loss
+
+    g = _load("losses.npz")
+    v = _t(g[f"v{B}"]).requires_grad_(True)
+    t = _t(g[f"t{B}"]).requires_grad_(True)
+    lt = torch.log(torch.tensor(0.07)).requires_grad_(True)
+    loss = contrastive_loss(v, t, lt, **kw)
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{name}{B}_loss"])) < 1e-6
+    assert np.allclose(v.grad.numpy(), g[f"{name}{B}_dv"], atol=1e-7)
+    assert np.allclose(t.grad.numpy(), g[f"{name}{B}_dt"], atol=1e-7)
+    assert abs(lt.grad.item() - float(g[f"{name}{B}_dlt"])) < 1e-5
+
+
+def test_known_answers_from_survey():
+    """Generator(0) randn(8,512) pairs, temperature 0.07."""
+    g = _load("losses.npz")
+    assert abs(float(g["contrastive8_loss"]) - 2.27005911) < 1e-6
+    assert abs(float(g["clip8_loss"]) - 2.27005911) < 1e-6
+    assert abs(float(g["siglip_gated8_loss"]) - 2.12487268) < 1e-6
+    assert abs(float(g["siglip_bce8_loss"]) - 1.25289905) < 1e-6
+    v, t = _t(g["v8"]), _t(g["t8"])
+    sim = torch.nn.functional.normalize(v, dim=1) @ torch.nn.functional.normalize(t, dim=1).t()
+    assert sim.argmax(1).tolist() == [4, 0, 6, 2, 6, 3, 4, 1]
+
+
+def test_bce_and_multipositive_match_reference():
+    from oracle.losses import runner_multipositive_loss, siglip_bce_loss
+
+    g = _load("losses.npz")
+    for B in (8, 24):
+        v, t = _t(g[f"v{B}"]).requires_grad_(True), _t(g[f"t{B}"]).requires_grad_(True)
+        lt = torch.log(torch.tensor(0.07)).requires_grad_(True)
+        bias = torch.tensor(-10.0, requires_grad=True)
+        loss = siglip_bce_loss(v, t, lt, bias)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"siglip_bce{B}_loss"])) < 1e-6
+        assert np.allclose(v.grad.numpy(), g[f"siglip_bce{B}_dv"], atol=1e-8)
+        assert abs(bias.grad.item() - float(g[f"siglip_bce{B}_dbias"])) < 1e-6
+    v, t = _t(g["mp_v"]).requires_grad_(True), _t(g["mp_t"]).requires_grad_(True)
+    lt = torch.log(torch.tensor(0.07)).requires_grad_(True)
+    mask, w = _t(g["mp_mask"]), _t(g["mp_w"])
+    bias = torch.tensor(-10.0, requires_grad=True)
+    loss = siglip_bce_loss(v, t, lt, bias, pos_mask=mask, pos_weights=w)
+    assert abs(loss.item() - float(g["mp_bce_loss"])) < 1e-6
+    loss, _, _ = runner_multipositive_loss(v, t, lt, mask, w, weighted=True)
+    assert abs(loss.item() - float(g["mp_wce_loss"])) < 1e-6
+    loss, _, _ = runner_multipositive_loss(v, t, lt, mask, w, weighted=False)
+    assert abs(loss.item() - float(g["mp_rbce_loss"])) < 1e-6
+
+
+def test_siglip_gating_inequality():
+    """tests/test_losses.py:78-94 of the reference: x * sigmoid(x) <= x for the cosine range."""
+    x = torch.linspace(-1, 1, 101)
+    assert torch.all(x * torch.sigmoid(x) <= x.clamp(min=0) + 1e-7)
+
+
+def test_rope_matches_reference():
+    from oracle.mvit import Rope3DOracle, rope_tables
+
+    g = _load("rope.npz")
+    cos, sin = rope_tables(8, 7, 7, 96, n_special=1)
+    assert np.allclose(cos.numpy(), g["cos"], atol=1e-6) and np.allclose(sin.numpy(), g["sin"], atol=1e-6)
+    tok = _t(g["tok"]).long()
+    q, k = _t(g["q"]), _t(g["k"])
+    from oracle.mvit import rotate_half
+
+    qr = q * cos[tok] + rotate_half(q) * sin[tok]
+    kr = k * cos[tok] + rotate_half(k) * sin[tok]
+    assert np.allclose(qr.numpy(), g["q_rot"], atol=1e-5) and np.allclose(kr.numpy(), g["k_rot"], atol=1e-5)
+    c2, s2 = rope_tables(8, 14, 14, 96, n_special=1)
+    sel = _t(g["sel"]).long()
+    q2 = _t(g["q2_sel"])
+    assert np.allclose((q2 * c2[sel] + rotate_half(q2) * s2[sel]).numpy(), g["q2_rot_sel"], atol=1e-5)
+    k2 = _t(g["k2_sel"])
+    assert np.allclose((k2 * cos[:8] + rotate_half(k2) * sin[:8]).numpy(), g["k2_rot_sel"], atol=1e-5)
+    assert Rope3DOracle(96).one(torch.zeros(1, 1, 393, 96), (8, 7, 7)).shape == (1, 1, 393, 96)
+
+
+def test_attention_pool_and_aggregator_match_reference():
+    from oracle.model import AggregatorOracle, AttentionPoolOracle, init_by_name
+
+    g = _load("pools.npz")
+    ap = init_by_name(AttentionPoolOracle(512, 8))
+    with torch.no_grad():
+        assert np.allclose(ap(_t(g["ap_x"])).numpy(), g["ap_y"], atol=2e-5)
+        ag = init_by_name(AggregatorOracle(512, 4, 2))
+        for n in (1, 4, 8):
+            assert np.allclose(ag(_t(g[f"ag_x{n}"])).numpy(), g[f"ag_y{n}"], atol=2e-5), n
+
+
+def test_bert_matches_hf():
+    from oracle.model import BertOracle, init_by_name
+
+    g = _load("bert.npz")
+    m = init_by_name(BertOracle(vocab=1000, layers=2, max_pos=64))
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    with torch.no_grad():
+        h = m(_t(g["ids"]), _t(g["mask"]))
+    assert np.allclose(h[:, 0].numpy(), g["cls"], atol=3e-5)
+    assert np.allclose(h[[0, 2], 5].numpy(), g["tok5"][[0, 2]], atol=3e-5)  # row 1, token 5 is valid too
+    assert np.allclose(h[1, 5].numpy(), g["tok5"][1], atol=3e-5)
+
+
+def test_retrieval_metrics_match_reference():
+    from oracle import metrics as M
+
+    g = _load("retrieval.npz")
+    sim, gt = g["sim"], list(range(100))
+    rec = M.recall_at_k(sim, gt, [1, 5, 10])
+    assert [rec["Recall@1"], rec["Recall@5"], rec["Recall@10"]] == pytest.approx(list(g["recall"]), abs=1e-12)
+    assert M.mrr(sim, gt)["MRR_V2T"] == pytest.approx(float(g["mrr"]), abs=1e-9)
+    assert M.mean_ap(sim, gt) == pytest.approx(float(g["map"]), abs=1e-7)
+    assert M.median_rank(sim, gt) == int(g["median"])
+    nd = M.ndcg_at_k(sim, gt, [5, 10])
+    assert [nd["NDCG@5_V2T"], nd["NDCG@10_V2T"]] == pytest.approx(list(g["ndcg"]), abs=1e-7)
+    # SURVEY §8c known answers for this seed
+    assert list(g["recall"]) == pytest.approx([0.0, 0.03, 0.07]) and int(g["median"]) == 50
+    assert float(g["mrr"]) == pytest.approx(0.0377008, abs=1e-6)
+    sim2 = g["sim2"]
+    gt2 = [[int(x) for x in row if x >= 0] for row in g["gt2"]]
+    rec2 = M.recall_at_k(sim2, gt2, [1, 3, 10])
+    assert [rec2["Recall@1"], rec2["Recall@3"], rec2["Recall@10"]] == pytest.approx(list(g["recall2"]), abs=1e-12)
+    assert M.mrr(sim2, gt2)["MRR_V2T"] == pytest.approx(float(g["mrr2"]), abs=1e-9)
+    assert M.mean_ap(sim2, gt2) == pytest.approx(float(g["map2"]), abs=1e-7)
+    assert M.median_rank(sim2, gt2) == int(g["median2"])
+    assert M.ndcg_at_k(sim2, gt2, [3])["NDCG@3_V2T"] == pytest.approx(float(g["ndcg2"][0]), abs=1e-7)
+
+
+def test_retrieval_known_answers_of_reference_tests():
+    """tests/test_retrieval_metrics.py:11-43,82-103 of the reference."""
+    from oracle import metrics as M
+
+    n = 5
+    perfect = np.eye(n) * 2 - 1
+    gt = list(range(n))
+    assert M.recall_at_k(perfect, gt, [1, 5])["Recall@1"] == 1.0
+    assert M.mrr(perfect, gt)["MRR_V2T"] == 1.0 and M.mean_ap(perfect, gt) == 1.0 and M.median_rank(perfect, gt) == 1
+    rev = np.fliplr(np.eye(n)) * 2 - 1
+    assert M.recall_at_k(rev, gt, [1])["Recall@1"] == pytest.approx(0.2)
+    assert M.mrr(rev, gt)["MRR_V2T"] < 0.5 and M.median_rank(rev, gt) > 2.5
+
+
+def test_mvit_structural_known_answers():
+    """torchvision's published MViT-v2-S figures: 34 537 744 params with the 400-way head, i.e. 34 230 144 without."""
+    from oracle.mvit import MViTv2S
+
+    m = MViTv2S(16, (224, 224))
+    assert sum(p.numel() for p in m.parameters()) == 34_230_144
+    assert sum(p.numel() for p in m.parameters()) + 768 * 400 + 400 == 34_537_744
+    keys = list(m.state_dict().keys())
+    for k in ("conv_proj.weight", "pos_encoding.class_token", "blocks.0.attn.rel_pos_h", "blocks.0.attn.pool_q.pool.weight",
+              "blocks.0.attn.pool_k.norm_act.0.weight", "blocks.1.project.weight", "blocks.15.mlp.3.bias", "norm.weight"):
+        assert k in keys, k
+    small = MViTv2S(4, (112, 112))
+    with torch.no_grad():
+        y = small.forward_features(torch.randn(1, 3, 4, 112, 112))
+    assert y.shape == (1, 33, 768)  # BASELINE config 1: L = 2*4*4 + 1
