@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--pooling", default="mean", choices=["mean", "attention"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-kernels", type=int, default=0, help="print the N slowest timed kernel shapes (stderr)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,6 +187,9 @@ def main():
         for _ in range(args.steps):
             runner._train_step(**batch)
         summ = K.TIMER.summary()
+        if args.dump_kernels and rank == 0:
+            for fam, lab, n, ms, units in K.TIMER.by_label()[: args.dump_kernels]:
+                print(f"[kernels] {fam:9s} {ms / args.steps:8.3f} ms/step {n // args.steps:4d}x  {units / max(ms, 1e-9) / 1e9:8.1f} TFLOP/s  {lab}", file=sys.stderr)
         K.TIMER = None
         fam = "gemm_bf16" if args.dtype == "bf16" else "gemm_f32"
         if fam in summ and summ[fam]["ms"] > 0:

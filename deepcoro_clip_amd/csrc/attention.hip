@@ -43,20 +43,40 @@ template <typename T, int D> struct RowTile {  // [rows][D] tile with padded pit
   static constexpr int CPR = D / CH;
 };
 
-// cooperative global -> LDS copy of `nrows` rows (zero-filled beyond n_valid)
+// Cooperative staging of a TK-row tile, split in two halves so that the global loads of tile t+1 are in flight
+// while tile t is being computed (register prefetch; a rolled load->wait->store loop serialises one HBM round
+// trip per 16-byte chunk and was the bottleneck of the first version).
+template <typename T, int D> struct TileRegs {
+  static constexpr int NCH = TK * RowTile<T, D>::CPR / ANT;  // 16-byte chunks per thread
+  vec16_t<T> v[NCH];
+};
+
 template <typename T, int D>
-__device__ __forceinline__ void stage_rows(char* lds, const T* base, int64_t row_stride, int row0, int n_valid,
-                                           int nrows, int tid) {
+__device__ __forceinline__ void tile_load(TileRegs<T, D>& r, const T* base, int64_t row_stride, int row0, int n_valid,
+                                          int tid) {
   using RT = RowTile<T, D>;
   using V = vec16_t<T>;
-  const int total = nrows * RT::CPR;
-  for (int id = tid; id < total; id += ANT) {
-    const int r = id / RT::CPR, c = id % RT::CPR;
+#pragma unroll
+  for (int i = 0; i < TileRegs<T, D>::NCH; ++i) {
+    const int id = tid + ANT * i;
+    const int rr = id / RT::CPR, c = id % RT::CPR;
     V v;
 #pragma unroll
     for (int e = 0; e < RT::CH; ++e) v[e] = (T)0.0f;
-    if (row0 + r < n_valid) v = *reinterpret_cast<const V*>(base + (int64_t)(row0 + r) * row_stride + c * RT::CH);
-    *reinterpret_cast<V*>(lds + r * RT::PITCH + c * 16) = v;
+    if (row0 + rr < n_valid) v = *reinterpret_cast<const V*>(base + (int64_t)(row0 + rr) * row_stride + c * RT::CH);
+    r.v[i] = v;
+  }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void tile_store(const TileRegs<T, D>& r, char* lds, int tid) {
+  using RT = RowTile<T, D>;
+  using V = vec16_t<T>;
+#pragma unroll
+  for (int i = 0; i < TileRegs<T, D>::NCH; ++i) {
+    const int id = tid + ANT * i;
+    const int rr = id / RT::CPR, c = id % RT::CPR;
+    *reinterpret_cast<V*>(lds + rr * RT::PITCH + c * 16) = r.v[i];
   }
 }
 
@@ -185,17 +205,26 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(AttnParams p) {
   float m = -INFINITY, l = 0.0f;
   const float scale2 = p.scale * LOG2E;
 
-  for (int kt0 = 0; kt0 < p.Nk; kt0 += TK) {
-    __syncthreads();
-    stage_rows<T, DQK>(ldsK, K, p.skn, kt0, p.Nk, TK, tid);
-    stage_rows<T, DV>(ldsV, V, p.svn, kt0, p.Nk, TK, tid);
+  TileRegs<T, DQK> rk;
+  TileRegs<T, DV> rv;
+  float rbias = -INFINITY;
+  auto prefetch = [&](int kt0) {
+    tile_load<T, DQK>(rk, K, p.skn, kt0, p.Nk, tid);
+    tile_load<T, DV>(rv, V, p.svn, kt0, p.Nk, tid);
     if (tid < TK) {
       const int key = kt0 + tid;
-      float bv = -INFINITY;
-      if (key < p.Nk) bv = p.kbias ? p.kbias[(int64_t)b * p.Nk + key] * LOG2E : 0.0f;
-      ldsB[tid] = bv;
+      rbias = -INFINITY;
+      if (key < p.Nk) rbias = p.kbias ? p.kbias[(int64_t)b * p.Nk + key] * LOG2E : 0.0f;
     }
+  };
+  prefetch(0);
+  for (int kt0 = 0; kt0 < p.Nk; kt0 += TK) {
+    __syncthreads();  // previous tile's fragment reads are done
+    tile_store<T, DQK>(rk, ldsK, tid);
+    tile_store<T, DV>(rv, ldsV, tid);
+    if (tid < TK) ldsB[tid] = rbias;
     __syncthreads();
+    if (kt0 + TK < p.Nk) prefetch(kt0 + TK);  // in flight during this tile's MFMAs
 #pragma unroll
     for (int sub = 0; sub < TK / 32; ++sub) {
       if (kt0 + 32 * sub >= p.Nk) break;
@@ -287,17 +316,26 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
     for (int e = 0; e < 16; ++e) dq[t][e] = 0.0f;
   const float scale2 = p.scale * LOG2E;
 
-  for (int kt0 = 0; kt0 < p.Nk; kt0 += TK) {
-    __syncthreads();
-    stage_rows<T, DQK>(ldsK, K, p.skn, kt0, p.Nk, TK, tid);
-    stage_rows<T, DV>(ldsV, V, p.svn, kt0, p.Nk, TK, tid);
+  TileRegs<T, DQK> rk;
+  TileRegs<T, DV> rv;
+  float rbias = -INFINITY;
+  auto prefetch = [&](int kt0) {
+    tile_load<T, DQK>(rk, K, p.skn, kt0, p.Nk, tid);
+    tile_load<T, DV>(rv, V, p.svn, kt0, p.Nk, tid);
     if (tid < TK) {
       const int key = kt0 + tid;
-      float bv = -INFINITY;
-      if (key < p.Nk) bv = p.kbias ? p.kbias[(int64_t)b * p.Nk + key] * LOG2E : 0.0f;
-      ldsB[tid] = bv;
+      rbias = -INFINITY;
+      if (key < p.Nk) rbias = p.kbias ? p.kbias[(int64_t)b * p.Nk + key] * LOG2E : 0.0f;
     }
+  };
+  prefetch(0);
+  for (int kt0 = 0; kt0 < p.Nk; kt0 += TK) {
     __syncthreads();
+    tile_store<T, DQK>(rk, ldsK, tid);
+    tile_store<T, DV>(rv, ldsV, tid);
+    if (tid < TK) ldsB[tid] = rbias;
+    __syncthreads();
+    if (kt0 + TK < p.Nk) prefetch(kt0 + TK);
 #pragma unroll
     for (int sub = 0; sub < TK / 32; ++sub) {
       if (kt0 + 32 * sub >= p.Nk) break;
@@ -324,8 +362,10 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
   }
   if (myq < p.Nq) {
     T* drow = reinterpret_cast<T*>(p.dQ) + b * p.sdqb + hd * p.sdqh + (int64_t)myq * p.sdqn;
+    // residual shortcut O += Qf[:, :DV] (q >= res_start): its gradient dO lands in the first DV columns of dQ
+    const T* rrow = (p.Qres && myq >= p.res_start) ? dO + (int64_t)myq * p.son : nullptr;
 #pragma unroll
-    for (int t = 0; t < DQK / 32; ++t) store_tile_T<T>(drow, t, h, dq[t], p.scale, nullptr);
+    for (int t = 0; t < DQK / 32; ++t) store_tile_T<T>(drow, t, h, dq[t], p.scale, (32 * t < DV) ? rrow : nullptr);
   }
 }
 
@@ -336,7 +376,10 @@ template <typename T, typename TO, int DQK, int DV>
 __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
   using QT = RowTile<T, DQK>;
   using OT = RowTile<T, DV>;
-  __shared__ __attribute__((aligned(16))) char smem[TK * QT::PITCH + TK * OT::PITCH + 2 * TK * 4];
+  constexpr int TPITCH = DQK + 4;  // fp32 pitch of the per-wave transposition tile of the split epilogue
+  constexpr int STAGE_BYTES = TK * QT::PITCH + TK * OT::PITCH + 2 * TK * 4;
+  constexpr int TRANS_BYTES = sizeof(TO) == 4 ? 4 * 32 * TPITCH * 4 : 0;
+  __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES > TRANS_BYTES ? STAGE_BYTES : TRANS_BYTES];
   char* ldsQ = smem;
   char* ldsO = smem + TK * QT::PITCH;
   float* ldsL = reinterpret_cast<float*>(smem + TK * QT::PITCH + TK * OT::PITCH);
@@ -379,20 +422,30 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
   const int qt_begin = qs * per;
   int qt_end = qt_begin + per; if (qt_end > qtiles) qt_end = qtiles;
 
+  TileRegs<T, DQK> rq;
+  TileRegs<T, DV> ro;
+  float rl = INFINITY, rd = 0.0f;
+  auto prefetch = [&](int qq0) {
+    tile_load<T, DQK>(rq, Q, p.sqn, qq0, p.Nq, tid);
+    tile_load<T, DV>(ro, dO, p.son, qq0, p.Nq, tid);
+    if (tid < TK) {
+      const int q = qq0 + tid;
+      rl = (q < p.Nq) ? LSE[q] * LOG2E : INFINITY;
+      rd = (q < p.Nq) ? Dv[q] : 0.0f;
+    }
+  };
+  if (qt_begin < qt_end) prefetch(qt_begin * TK);
   for (int qt = qt_begin; qt < qt_end; ++qt) {
     const int qq0 = qt * TK;
     __syncthreads();
-    stage_rows<T, DQK>(ldsQ, Q, p.sqn, qq0, p.Nq, TK, tid);
-    stage_rows<T, DV>(ldsO, dO, p.son, qq0, p.Nq, TK, tid);
-    if (tid < TK) {
-      const int q = qq0 + tid;
-      ldsL[tid] = (q < p.Nq) ? LSE[q] * LOG2E : INFINITY;
-      ldsD[tid] = (q < p.Nq) ? Dv[q] : 0.0f;
-    }
+    tile_store<T, DQK>(rq, ldsQ, tid);
+    tile_store<T, DV>(ro, ldsO, tid);
+    if (tid < TK) { ldsL[tid] = rl; ldsD[tid] = rd; }
     __syncthreads();
+    if (qt + 1 < qt_end) prefetch(qq0 + TK);
 #pragma unroll
     for (int sub = 0; sub < TK / 32; ++sub) {
-      if (qq0 + 32 * sub >= p.Nq) break;
+      if (qq0 + 32 * sub >= p.Nq || k0 >= p.Nk) break;  // no queries left / this wave owns no valid key
       f32x16 S, dP;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { S[e] = 0.0f; dP[e] = 0.0f; }
@@ -422,24 +475,44 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
     }
   }
 
-  if (mykey < p.Nk) {
-    TO* dkrow = reinterpret_cast<TO*>(p.dK) + b * p.sdkb + hd * p.sdkh + (int64_t)mykey * p.sdkn;
-    TO* dvrow = reinterpret_cast<TO*>(p.dV) + b * p.sdvb + hd * p.sdvh + (int64_t)mykey * p.sdvn;
-    if (p.qsplit == 1) {
+  if (p.qsplit == 1) {
+    if (mykey < p.Nk) {
+      TO* dkrow = reinterpret_cast<TO*>(p.dK) + b * p.sdkb + hd * p.sdkh + (int64_t)mykey * p.sdkn;
+      TO* dvrow = reinterpret_cast<TO*>(p.dV) + b * p.sdvb + hd * p.sdvh + (int64_t)mykey * p.sdvn;
 #pragma unroll
       for (int t = 0; t < DQK / 32; ++t) store_tile_T<TO>(dkrow, t, h, dk[t], p.scale, nullptr);
 #pragma unroll
       for (int t = 0; t < DV / 32; ++t) store_tile_T<TO>(dvrow, t, h, dvv[t], 1.0f, nullptr);
-    } else if constexpr (sizeof(TO) == 4) {
+    }
+  } else if constexpr (sizeof(TO) == 4) {
+    // query-split partial sums: transpose each wave's [32 keys][D] tile through LDS so that one atomic
+    // wave-instruction covers 256 contiguous bytes of ONE row (row-per-lane atomics run ~17x slower)
+    __syncthreads();  // all waves are done with the staged Q / dO tiles
+    float* tw = reinterpret_cast<float*>(smem) + wave * (32 * TPITCH);
+    // dK
 #pragma unroll
-      for (int t = 0; t < DQK / 32; ++t)
+    for (int t = 0; t < DQK / 32; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          atomicAdd(reinterpret_cast<float*>(dkrow) + 32 * t + acc_row(e, h), dk[t][e] * p.scale);
+      for (int e = 0; e < 16; ++e) tw[(lane & 31) * TPITCH + 32 * t + acc_row(e, h)] = dk[t][e] * p.scale;
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+    for (int r = 0; r < 32; ++r) {
+      const int key = k0 + r;
+      if (key >= p.Nk) break;
+      float* dst = reinterpret_cast<float*>(p.dK) + b * p.sdkb + hd * p.sdkh + (int64_t)key * p.sdkn;
+      for (int c = lane; c < DQK; c += 64) atomicAdd(dst + c, tw[r * TPITCH + c]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // dV
 #pragma unroll
-      for (int t = 0; t < DV / 32; ++t)
+    for (int t = 0; t < DV / 32; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) atomicAdd(reinterpret_cast<float*>(dvrow) + 32 * t + acc_row(e, h), dvv[t][e]);
+      for (int e = 0; e < 16; ++e) tw[(lane & 31) * TPITCH + 32 * t + acc_row(e, h)] = dvv[t][e];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for (int r = 0; r < 32; ++r) {
+      const int key = k0 + r;
+      if (key >= p.Nk) break;
+      float* dst = reinterpret_cast<float*>(p.dV) + b * p.sdvb + hd * p.sdvh + (int64_t)key * p.sdvn;
+      for (int c = lane; c < DV; c += 64) atomicAdd(dst + c, tw[r * TPITCH + c]);
     }
   }
 }

@@ -272,10 +272,20 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const TD* __rest
         }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < taps * g.C; i += blockDim.x) {
-    const int k = i / g.C, cc = i % g.C;
-    atomicAdd(dw + cc * taps + k, red[i]);
-  }
+  // per-block partial -> workspace (plain coalesced stores); dwconv_reduce_kernel folds the blocks.
+  // (global atomics here meant gridDim x taps x C adds onto the same 2592 addresses: contention-bound)
+  float* part = dw + (int64_t)blockIdx.x * taps * g.C;
+  for (int i = threadIdx.x; i < taps * g.C; i += blockDim.x) part[i] = red[i];
+}
+
+// dw[c][tap] += sum_b ws[b][tap][c]
+__global__ void dwconv_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblocks, int taps, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= taps * C) return;
+  float acc = 0.0f;
+  for (int b = 0; b < nblocks; ++b) acc += ws[(int64_t)b * taps * C + i];
+  const int k = i / C, cc = i % C;
+  dw[cc * taps + k] += acc;
 }
 
 inline unsigned blocks_for(int64_t total, int per_block, int cap) {
@@ -372,25 +382,29 @@ extern "C" int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const
   return dcc_check_launch();
 }
 
-// dw [C][taps] fp32 is ACCUMULATED into.
-extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, const int* dims, const int64_t* strides,
-                                     int dtype, int grad_dtype, void* stream) {
-  if (!dy || !x || !dw || !dims || !strides) return DCC_ERR_ARG;
+// dw [C][taps] fp32 is ACCUMULATED into.  workspace: fp32 [DCC_DWCONV_WS_BLOCKS * taps * C] scratch (no init needed).
+extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, float* workspace, const int* dims,
+                                     const int64_t* strides, int dtype, int grad_dtype, void* stream) {
+  if (!dy || !x || !dw || !workspace || !dims || !strides) return DCC_ERR_ARG;
   PoolGeom g = make_geom(dims, strides);
   int rc = geom_ok(g, 4);
   if (rc) return rc;
   if (g.C / 4 > 256) return DCC_ERR_UNSUPPORTED;
   const int slots = 256 / (g.C / 4);
+  const int taps = g.kt * g.kh * g.kw;
   const int64_t total = (int64_t)g.B * g.H * g.To * g.Ho * g.Wo;
-  dim3 grid(blocks_for(total, slots * 8, 1024));
-  const size_t lds = (size_t)g.kt * g.kh * g.kw * g.C * 4;
+  dim3 grid(blocks_for(total, slots * 4, 256));  // <= DCC_DWCONV_WS_BLOCKS
+  const size_t lds = (size_t)taps * g.C * 4;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DCC_BF16 && grad_dtype == DCC_BF16)
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, dw, g);
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, workspace, g);
   else if (dtype == DCC_BF16 && grad_dtype == DCC_F32)
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, float>), grid, dim3(256), lds, s, (const float*)dy, (const bf16_t*)x, dw, g);
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, float>), grid, dim3(256), lds, s, (const float*)dy, (const bf16_t*)x, workspace, g);
   else if (dtype == DCC_F32 && grad_dtype == DCC_F32)
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<float, float>), grid, dim3(256), lds, s, (const float*)dy, (const float*)x, dw, g);
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<float, float>), grid, dim3(256), lds, s, (const float*)dy, (const float*)x, workspace, g);
   else return DCC_ERR_UNSUPPORTED;
+  rc = dcc_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((taps * g.C + 255) / 256), dim3(256), 0, s, workspace, dw, (int)grid.x, taps, g.C);
   return dcc_check_launch();
 }

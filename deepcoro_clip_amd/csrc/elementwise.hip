@@ -312,8 +312,8 @@ extern "C" int dcc_dgelu_mul(const void* dy, const void* pre, void* out, int64_t
 
 extern "C" int dcc_colsum(const void* x, int64_t ldx, float* out, int64_t M, int N, int dtype, void* stream) {
   if (!x || !out || M <= 0 || N <= 0 || N > 8192) return DCC_ERR_ARG;
-  int64_t blocks = (M + 63) / 64;
-  if (blocks > 1024) blocks = 1024;
+  int64_t blocks = (M + 255) / 256;
+  if (blocks > 256) blocks = 256;  // each block ends with N global atomics
   dim3 g((unsigned)blocks);
   if (dtype == DCC_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), g, dim3(256), N * 4, ST, (const bf16_t*)x, ldx, out, M, N);
   else if (dtype == DCC_F32) hipLaunchKernelGGL((colsum_kernel<float>), g, dim3(256), N * 4, ST, (const float*)x, ldx, out, M, N);

@@ -4,12 +4,14 @@
 // so that a Linear layer's forward (x W^T), data gradient (dy W) and weight gradient
 // (dy^T x) are the three layout variants of one kernel, with no transposes through HBM.
 //
-// Tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles.
-// Operands go global -> registers (16-byte coalesced chunks) -> LDS, double buffered.
-// "k-contiguous" operands live in LDS as [row][32 k] with rows padded by 16 B (odd multiple of
-// 16 B => conflict-free ds_read_b128 fragment reads); "k-major" operands live as [k][128] and
-// are read with ds_read_b64_tr_b16 (bf16, 256-byte rows, XOR-swizzled 16-byte chunks) or plain
-// ds_read_b32 (fp32).
+// Block tile (64*TM)^2 x BK (BK = 64 bf16 / 32 fp32), 256 threads = 4 waves (2x2), each wave a TM x TM grid of
+// 32x32 MFMA tiles.  Operands go global -> registers (16-byte coalesced chunks, prefetched one K-tile ahead) ->
+// LDS (double buffered, one barrier per K-tile).  "k-contiguous" operands live in LDS as [row][BK] with rows padded
+// by 16 B (odd multiple of 16 B => conflict-free ds_read_b128 fragment reads); "k-major" operands live as [k][cols]
+// and are read with ds_read_b64_tr_b16 (bf16, XOR-swizzled 16-byte chunks) or plain ds_read_b32 (fp32).
+// Epilogue: accumulators are staged through LDS as fp32 and written as whole 16-byte chunks of complete rows
+// (bias / GELU / GELU' / residual applied in that coalesced layout); split-K and accumulate modes use fp32 atomics.
+// Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles.
 #include "common.h"
 
 #define GEMM_BIAS 1
@@ -18,6 +20,7 @@
 #define GEMM_RESID 8
 #define GEMM_DGELU 16
 #define GEMM_ACCUM 32
+#define GEMM_COLSUM_A 64
 
 struct GemmParams {
   const void* A;
@@ -26,37 +29,47 @@ struct GemmParams {
   const float* bias;
   const void* R;
   void* aux;
+  float* colsum;  // GEMM_COLSUM_A: colsum[m] += sum_k A(m,k)   (bias gradient fused into the weight-gradient GEMM)
   int64_t lda, ldb, ldc, ldr, ldaux;
   int64_t sA, sB, sC;
   int M, N, K;
   int batch, splitk;
   float alpha;
   int flags;
-  int unaligned;  // 1: operands break the 16-byte chunk rules -> element-wise guarded loads
 };
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+constexpr int NT = 256;
 
-template <typename T, bool KM> struct OpTile {
+template <typename T> struct KTile { static constexpr int BK = sizeof(T) == 2 ? 64 : 32; };
+
+template <typename T, bool KM, int TM> struct OpTile {
   static constexpr int ES = sizeof(T);
-  static constexpr int CH = 16 / ES;                       // elements per 16-byte chunk
-  static constexpr int ROWB = KM ? 128 * ES : BK * ES + 16;  // LDS row pitch in bytes
-  static constexpr int ROWS = KM ? BK : 128;
+  static constexpr int BK = KTile<T>::BK;
+  static constexpr int W = 64 * TM;                         // tile extent in the non-reduction dimension
+  static constexpr int CH = 16 / ES;                        // elements per 16-byte chunk
+  static constexpr int ROWB = KM ? W * ES : BK * ES + 16;   // LDS row pitch in bytes
+  static constexpr int ROWS = KM ? BK : W;
   static constexpr int BYTES = ROWS * ROWB;
-  static constexpr int NCH = 128 * BK * ES / 16 / NT;      // chunks per thread
-  static constexpr int CPR = KM ? 128 / CH : BK / CH;      // chunks per LDS row
+  static constexpr int NCH = W * BK * ES / 16 / NT;         // chunks per thread
+  static constexpr int CPR = KM ? W / CH : BK / CH;         // chunks per LDS row
 };
 
-__device__ __forceinline__ int swz_km(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
+// XOR swizzle of the 16-byte chunk index for k-major bf16 tiles (conflict-free ds_read_b64_tr_b16):
+// 256-byte rows (W=128): 4 rows of a read block land in 4 different 64-byte quarters of the bank row;
+// 128-byte rows (W=64): rows 2,3 of a block use the other 64-byte half.
+template <int W> __device__ __forceinline__ int swz_km(int krow) {
+  if constexpr (W == 128) return ((krow & 3) << 2) | ((krow >> 2) & 3);
+  else return ((krow >> 1) & 1) << 2;
+}
 
 // global -> registers. `row0` is the tile origin in the non-reduction dimension, `dim` its extent.
-template <typename T, bool KM>
+template <typename T, bool KM, int TM, bool ALIGNED>
 __device__ __forceinline__ void g2r(vec16_t<T>* regs, const T* base, int64_t ld, int row0, int dim, int k0, int kend,
-                                    int tid, bool unaligned) {
-  using OT = OpTile<T, KM>;
-  using V = typename Vec16<T>::type;
+                                    int tid) {
+  using OT = OpTile<T, KM, TM>;
+  using V = vec16_t<T>;
 #pragma unroll
   for (int i = 0; i < OT::NCH; ++i) {
     const int id = tid + NT * i;
@@ -68,7 +81,7 @@ __device__ __forceinline__ void g2r(vec16_t<T>* regs, const T* base, int64_t ld,
       const int gr = row0 + r, gk = k0 + c * OT::CH;
       if (gr < dim && gk < kend) {
         const T* src = base + (int64_t)gr * ld + gk;
-        if (!unaligned) v = *reinterpret_cast<const V*>(src);
+        if constexpr (ALIGNED) v = *reinterpret_cast<const V*>(src);
         else {
 #pragma unroll
           for (int e = 0; e < OT::CH; ++e)
@@ -79,7 +92,7 @@ __device__ __forceinline__ void g2r(vec16_t<T>* regs, const T* base, int64_t ld,
       const int gk = k0 + r, gc = row0 + c * OT::CH;
       if (gk < kend && gc < dim) {
         const T* src = base + (int64_t)gk * ld + gc;
-        if (!unaligned) v = *reinterpret_cast<const V*>(src);
+        if constexpr (ALIGNED) v = *reinterpret_cast<const V*>(src);
         else {
 #pragma unroll
           for (int e = 0; e < OT::CH; ++e)
@@ -91,28 +104,27 @@ __device__ __forceinline__ void g2r(vec16_t<T>* regs, const T* base, int64_t ld,
   }
 }
 
-template <typename T, bool KM>
+template <typename T, bool KM, int TM>
 __device__ __forceinline__ void r2s(const vec16_t<T>* regs, char* buf, int tid) {
-  using OT = OpTile<T, KM>;
-  using V = typename Vec16<T>::type;
+  using OT = OpTile<T, KM, TM>;
+  using V = vec16_t<T>;
 #pragma unroll
   for (int i = 0; i < OT::NCH; ++i) {
     const int id = tid + NT * i;
     const int r = id / OT::CPR, c = id % OT::CPR;
     int off;
-    if (!KM) off = r * OT::ROWB + c * 16;
-    else if (sizeof(T) == 2) off = r * OT::ROWB + ((c ^ swz_km(r)) * 16);
+    if (KM && sizeof(T) == 2) off = r * OT::ROWB + ((c ^ swz_km<OT::W>(r)) * 16);
     else off = r * OT::ROWB + c * 16;
     *reinterpret_cast<V*>(buf + off) = regs[i];
   }
 }
 
 // fragment of K-step s (16 k) for the 32 rows/cols starting at `t0` of the tile.
-template <typename T, bool KM>
-__device__ __forceinline__ typename Frag<T>::type load_frag(const char* buf, int t0, int s, int lane) {
-  using OT = OpTile<T, KM>;
+template <typename T, bool KM, int TM>
+__device__ __forceinline__ frag_t<T> load_frag(const char* buf, int t0, int s, int lane) {
+  using OT = OpTile<T, KM, TM>;
   const int r = lane & 31, h = lane >> 5;
-  typename Frag<T>::type f;
+  frag_t<T> f;
   if constexpr (!KM) {
     const char* p = buf + (t0 + r) * OT::ROWB + (16 * s + 8 * h) * OT::ES;
     if constexpr (sizeof(T) == 2) {
@@ -129,7 +141,7 @@ __device__ __forceinline__ typename Frag<T>::type load_frag(const char* buf, int
     for (int half = 0; half < 2; ++half) {
       const int krow = 16 * s + 8 * h + 4 * half + q;
       const int chunk = ((t0 + 16 * g) >> 3) + (pp >> 1);
-      const char* p = buf + krow * OT::ROWB + ((chunk ^ swz_km(krow)) * 16) + 8 * (pp & 1);
+      const char* p = buf + krow * OT::ROWB + ((chunk ^ swz_km<OT::W>(krow)) * 16) + 8 * (pp & 1);
       const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
       const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
       f[4 * half + 0] = tb[0]; f[4 * half + 1] = tb[1]; f[4 * half + 2] = tb[2]; f[4 * half + 3] = tb[3];
@@ -142,19 +154,31 @@ __device__ __forceinline__ typename Frag<T>::type load_frag(const char* buf, int
   return f;
 }
 
-template <typename T, typename TC, bool A_KM, bool B_KM>
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <typename T, typename TC, bool A_KM, bool B_KM, int TM, bool ALIGNED>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
-  using OA = OpTile<T, A_KM>;
-  using OB = OpTile<T, B_KM>;
-  __shared__ __attribute__((aligned(16))) char smem[2 * (OA::BYTES + OB::BYTES)];
+  using OA = OpTile<T, A_KM, TM>;
+  using OB = OpTile<T, B_KM, TM>;
+  constexpr int BK = KTile<T>::BK;
+  constexpr int BMN = 64 * TM;
   constexpr int STAGE = OA::BYTES + OB::BYTES;
+  constexpr int CPITCH = BMN + 4;                       // fp32 staging pitch of the epilogue (floats)
+  constexpr int SMEM = cmax(2 * STAGE, BMN * CPITCH * 4);
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int tilesN = (p.N + BN - 1) / BN;
-  const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
+  const int tilesN = (p.N + BMN - 1) / BMN;
+  // XCD-aware remap: hardware deals workgroups round-robin over 8 XCDs; give each XCD a contiguous tile range
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / tilesN, tn = bid % tilesN;
   const int bz = blockIdx.z / p.splitk, sk = blockIdx.z % p.splitk;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BMN, n0 = tn * BMN;
 
   const T* A = reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.sA;
   const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.sB;
@@ -166,20 +190,31 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
   const int kend = (ks1 * BK < p.K) ? ks1 * BK : p.K;
   const int nk = ks1 - ks0;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  typename Vec16<T>::type ra[OA::NCH], rb[OB::NCH];
+  const bool do_colsum = A_KM && (p.flags & GEMM_COLSUM_A) && tn == 0;
+  float csum[OA::CH];
+#pragma unroll
+  for (int e = 0; e < OA::CH; ++e) csum[e] = 0.0f;
+
+  vec16_t<T> ra[OA::NCH], rb[OB::NCH];
   if (nk > 0) {
-    g2r<T, A_KM>(ra, A, p.lda, m0, p.M, ks0 * BK, kend, tid, p.unaligned);
-    g2r<T, B_KM>(rb, B, p.ldb, n0, p.N, ks0 * BK, kend, tid, p.unaligned);
-    r2s<T, A_KM>(ra, smem, tid);
-    r2s<T, B_KM>(rb, smem + OA::BYTES, tid);
+    g2r<T, A_KM, TM, ALIGNED>(ra, A, p.lda, m0, p.M, ks0 * BK, kend, tid);
+    g2r<T, B_KM, TM, ALIGNED>(rb, B, p.ldb, n0, p.N, ks0 * BK, kend, tid);
+    r2s<T, A_KM, TM>(ra, smem, tid);
+    r2s<T, B_KM, TM>(rb, smem + OA::BYTES, tid);
+    if (A_KM && do_colsum) {
+#pragma unroll
+      for (int i = 0; i < OA::NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < OA::CH; ++e) csum[e] += to_f32(ra[i][e]);
+    }
   }
   __syncthreads();
 
@@ -189,68 +224,166 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     char* curB = curA + OA::BYTES;
     char* nxtA = smem + (cur ^ 1) * STAGE;
     char* nxtB = nxtA + OA::BYTES;
-    if (kt + 1 < nk) {
-      g2r<T, A_KM>(ra, A, p.lda, m0, p.M, (ks0 + kt + 1) * BK, kend, tid, p.unaligned);
-      g2r<T, B_KM>(rb, B, p.ldb, n0, p.N, (ks0 + kt + 1) * BK, kend, tid, p.unaligned);
+    const bool more = kt + 1 < nk;
+    if (more) {
+      g2r<T, A_KM, TM, ALIGNED>(ra, A, p.lda, m0, p.M, (ks0 + kt + 1) * BK, kend, tid);
+      g2r<T, B_KM, TM, ALIGNED>(rb, B, p.ldb, n0, p.N, (ks0 + kt + 1) * BK, kend, tid);
     }
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      typename Frag<T>::type fa[2], fb[2];
+      frag_t<T> fa[TM], fb[TM];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = load_frag<T, A_KM>(curA, wr * 64 + 32 * i, s, lane);
+      for (int i = 0; i < TM; ++i) fa[i] = load_frag<T, A_KM, TM>(curA, wr * 32 * TM + 32 * i, s, lane);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = load_frag<T, B_KM>(curB, wc * 64 + 32 * j, s, lane);
+      for (int j = 0; j < TM; ++j) fb[j] = load_frag<T, B_KM, TM>(curB, wc * 32 * TM + 32 * j, s, lane);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < TM; ++j) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
     }
-    if (kt + 1 < nk) {
-      r2s<T, A_KM>(ra, nxtA, tid);
-      r2s<T, B_KM>(rb, nxtB, tid);
+    if (more) {
+      r2s<T, A_KM, TM>(ra, nxtA, tid);
+      r2s<T, B_KM, TM>(rb, nxtB, tid);
+      if (A_KM && do_colsum) {
+#pragma unroll
+        for (int i = 0; i < OA::NCH; ++i)
+#pragma unroll
+          for (int e = 0; e < OA::CH; ++e) csum[e] += to_f32(ra[i][e]);
+      }
     }
     __syncthreads();
   }
 
-  // epilogue
   TC* C = reinterpret_cast<TC*>(p.C) + (int64_t)bz * p.sC;
-  const TC* R = reinterpret_cast<const TC*>(p.R);
   const bool atomic = (p.splitk > 1) || (p.flags & GEMM_ACCUM);
   const int h = lane >> 5;
+
+  if (A_KM && do_colsum) {
+    // all chunks of a thread share one column chunk (NT is a multiple of CPR): fold the k-rows through LDS
+    float* red = reinterpret_cast<float*>(smem);
+    for (int i = tid; i < BMN; i += NT) red[i] = 0.0f;
+    __syncthreads();
+    const int c = tid % OA::CPR;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+    for (int e = 0; e < OA::CH; ++e) atomicAdd(&red[c * OA::CH + e], csum[e]);
+    __syncthreads();
+    for (int i = tid; i < BMN; i += NT)
+      if (m0 + i < p.M) atomicAdd(p.colsum + m0 + i, red[i]);
+    __syncthreads();
+  }
+
+  if (atomic) {
+    if constexpr (sizeof(TC) == 4) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wc * 64 + 32 * j + (lane & 31);
-      if (col >= p.N) continue;
-      float bv = 0.0f;
-      if ((p.flags & GEMM_BIAS) && sk == 0) bv = p.bias[col];
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wr * 64 + 32 * i + acc_row(e, h);
-        if (row >= p.M) continue;
-        float v = acc[i][j][e] * p.alpha + bv;
-        if (p.flags & GEMM_SAVE_PRE) reinterpret_cast<TC*>(p.aux)[(int64_t)row * p.ldaux + col] = from_f32<TC>(v);
-        if (p.flags & GEMM_GELU) v = gelu_f(v);
-        if (p.flags & GEMM_DGELU) v *= dgelu_f(to_f32(reinterpret_cast<const T*>(p.aux)[(int64_t)row * p.ldaux + col]));
-        if (p.flags & GEMM_RESID) v += to_f32(R[(int64_t)row * p.ldr + col]);
-        TC* dst = C + (int64_t)row * p.ldc + col;
-        if (atomic) {
-          if constexpr (sizeof(TC) == 4) atomicAdd(reinterpret_cast<float*>(dst), v);
-        } else {
-          *dst = from_f32<TC>(v);
+        for (int j = 0; j < TM; ++j) {
+          const int col = n0 + wc * 32 * TM + 32 * j + (lane & 31);
+          if (col >= p.N) continue;
+          const float bv = ((p.flags & GEMM_BIAS) && sk == 0) ? p.bias[col] : 0.0f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wr * 32 * TM + 32 * i + acc_row(e, h);
+            if (row < p.M) atomicAdd(reinterpret_cast<float*>(C) + (int64_t)row * p.ldc + col, acc[i][j][e] * p.alpha + bv);
+          }
         }
+    }
+    return;
+  }
+
+  // stage the fp32 tile in LDS (the K loop's last barrier has retired all fragment reads), then walk it row-major
+  float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        ct[(wr * 32 * TM + 32 * i + acc_row(e, h)) * CPITCH + wc * 32 * TM + 32 * j + (lane & 31)] = acc[i][j][e];
+  __syncthreads();
+  constexpr int GPR = BMN / 8;  // 8-column groups per tile row
+  const TC* R = reinterpret_cast<const TC*>(p.R);
+  for (int gidx = tid; gidx < BMN * GPR; gidx += NT) {
+    const int r = gidx / GPR, cg = gidx % GPR;
+    const int row = m0 + r, col = n0 + cg * 8;
+    if (row >= p.M || col >= p.N) continue;
+    float v[8];
+    {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(ct + r * CPITCH + cg * 8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + r * CPITCH + cg * 8 + 4);
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    }
+    const bool full = ALIGNED && (col + 8 <= p.N);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] *= p.alpha;
+      if ((p.flags & GEMM_BIAS) && col + e < p.N) v[e] += p.bias[col + e];
+    }
+    if (p.flags & GEMM_SAVE_PRE) {
+      TC* ap = reinterpret_cast<TC*>(p.aux) + (int64_t)row * p.ldaux + col;
+      if (full && sizeof(TC) == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+        *reinterpret_cast<bf16x8*>(ap) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (col + e < p.N) ap[e] = from_f32<TC>(v[e]);
       }
+    }
+    if (p.flags & GEMM_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    }
+    if (p.flags & GEMM_DGELU) {
+      const T* ap = reinterpret_cast<const T*>(p.aux) + (int64_t)row * p.ldaux + col;
+      if (full && sizeof(T) == 2) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)a[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (col + e < p.N) v[e] *= dgelu_f(to_f32(ap[e]));
+      }
+    }
+    if (p.flags & GEMM_RESID) {
+      const TC* rp = R + (int64_t)row * p.ldr + col;
+      if (full && sizeof(TC) == 2) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(rp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)a[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (col + e < p.N) v[e] += to_f32(rp[e]);
+      }
+    }
+    TC* dst = C + (int64_t)row * p.ldc + col;
+    if (full && sizeof(TC) == 2) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      *reinterpret_cast<bf16x8*>(dst) = o;
+    } else if (full && sizeof(TC) == 4) {
+      f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<f32x4*>(dst) = lo;
+      *reinterpret_cast<f32x4*>(dst + 4) = hi;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (col + e < p.N) dst[e] = from_f32<TC>(v[e]);
     }
   }
 }
 
-template <typename T, typename TC>
+template <typename T, typename TC, int TM, bool ALIGNED>
 int launch_layout(const GemmParams& p, int a_km, int b_km, dim3 grid, hipStream_t st) {
-  if (!a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false>), grid, dim3(NT), 0, st, p);
-  else if (!a_km && b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true>), grid, dim3(NT), 0, st, p);
-  else if (a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, true, false>), grid, dim3(NT), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<T, TC, true, true>), grid, dim3(NT), 0, st, p);
+  if (!a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false, TM, ALIGNED>), grid, dim3(NT), 0, st, p);
+  else if (!a_km && b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true, TM, ALIGNED>), grid, dim3(NT), 0, st, p);
+  else if (a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, true, false, TM, ALIGNED>), grid, dim3(NT), 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, TC, true, true, TM, ALIGNED>), grid, dim3(NT), 0, st, p);
   return dcc_check_launch();
 }
 
@@ -258,32 +391,48 @@ int launch_layout(const GemmParams& p, int a_km, int b_km, dim3 grid, hipStream_
 
 // See include/dcc.h for the contract.
 extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias, const void* R, void* aux,
-                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldaux, int M, int N, int K,
-                        int batch, int64_t sA, int64_t sB, int64_t sC, int splitk, float alpha, int flags, int a_km,
-                        int b_km, int in_dtype, int out_dtype, void* stream) {
+                        float* colsum, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldaux, int M, int N,
+                        int K, int batch, int64_t sA, int64_t sB, int64_t sC, int splitk, float alpha, int flags,
+                        int a_km, int b_km, int in_dtype, int out_dtype, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0) return DCC_ERR_ARG;
   if (!A || !B || !C) return DCC_ERR_ARG;
   const int ch = in_dtype == DCC_BF16 ? 8 : 4;
-  // 16-byte chunk loads need chunk-multiple pitches/extents and 16-byte aligned bases; otherwise fall back to
-  // element-wise guarded loads (tiny loss-side GEMMs with odd batch sizes land here)
-  int unaligned = 0;
-  if ((lda % ch) || (ldb % ch)) unaligned = 1;
-  if ((!a_km && (K % ch)) || (a_km && (M % ch))) unaligned = 1;
-  if ((!b_km && (K % ch)) || (b_km && (N % ch))) unaligned = 1;
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) unaligned = 1;
-  if ((sA % ch) || (sB % ch)) unaligned = 1;
+  // 16-byte chunk accesses need chunk-multiple pitches/extents and 16-byte aligned bases; otherwise the
+  // element-wise guarded variant runs (tiny loss-side fp32 GEMMs with odd batch sizes land there)
+  bool aligned = true;
+  if ((lda % ch) || (ldb % ch) || (sA % ch) || (sB % ch)) aligned = false;
+  if ((!a_km && (K % ch)) || (a_km && (M % ch))) aligned = false;
+  if ((!b_km && (K % ch)) || (b_km && (N % ch))) aligned = false;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) aligned = false;
+  const int och = 8;
+  if ((ldc % och) || (N % och) || (sC % och)) aligned = false;
+  if ((flags & GEMM_RESID) && ((ldr % och) || ((uintptr_t)R & 15))) aligned = false;
+  if ((flags & (GEMM_SAVE_PRE | GEMM_DGELU)) && ((ldaux % och) || ((uintptr_t)aux & 15))) aligned = false;
   if ((splitk > 1 || (flags & GEMM_ACCUM)) && out_dtype != DCC_F32) return DCC_ERR_ARG;
   if ((flags & GEMM_BIAS) && !bias) return DCC_ERR_ARG;
   if ((flags & GEMM_RESID) && !R) return DCC_ERR_ARG;
   if ((flags & (GEMM_SAVE_PRE | GEMM_DGELU)) && !aux) return DCC_ERR_ARG;
-  if (splitk > 1 && (flags & ~(GEMM_BIAS | GEMM_ACCUM))) return DCC_ERR_ARG;  // non-linear epilogues need the full sum
-  GemmParams p{A, B, C, bias, R, aux, lda, ldb, ldc, ldr, ldaux, sA, sB, sC, M, N, K, batch, splitk, alpha, flags, unaligned};
-  const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  if (tiles > 0x7fffffffLL || (int64_t)batch * splitk > 65535) return DCC_ERR_ARG;
-  dim3 grid((unsigned)tiles, 1, (unsigned)(batch * splitk));
+  if ((flags & GEMM_COLSUM_A) && (!colsum || !a_km || batch != 1)) return DCC_ERR_ARG;
+  if (splitk > 1 && (flags & ~(GEMM_BIAS | GEMM_ACCUM | GEMM_COLSUM_A))) return DCC_ERR_ARG;  // non-linear epilogues need the full sum
+  if (!aligned && in_dtype != DCC_F32) return DCC_ERR_UNSUPPORTED;  // bf16 callers always meet the chunk rules
+  GemmParams p{A, B, C, bias, R, aux, colsum, lda, ldb, ldc, ldr, ldaux, sA, sB, sC, M, N, K, batch, splitk, alpha, flags};
+  if ((int64_t)batch * splitk > 65535) return DCC_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (in_dtype == DCC_BF16 && out_dtype == DCC_BF16) return launch_layout<bf16_t, bf16_t>(p, a_km, b_km, grid, st);
-  if (in_dtype == DCC_BF16 && out_dtype == DCC_F32) return launch_layout<bf16_t, float>(p, a_km, b_km, grid, st);
-  if (in_dtype == DCC_F32 && out_dtype == DCC_F32) return launch_layout<float, float>(p, a_km, b_km, grid, st);
+  // tile choice: 128x128 unless that leaves most of the 256 CUs idle
+  const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch * splitk;
+  const bool small = in_dtype == DCC_BF16 && t128 < 192;
+  const int bmn = small ? 64 : 128;
+  const int64_t tiles = (int64_t)((M + bmn - 1) / bmn) * ((N + bmn - 1) / bmn);
+  if (tiles > 0x7fffffffLL) return DCC_ERR_ARG;
+  dim3 grid((unsigned)tiles, 1, (unsigned)(batch * splitk));
+  if (in_dtype == DCC_BF16 && out_dtype == DCC_BF16)
+    return small ? launch_layout<bf16_t, bf16_t, 1, true>(p, a_km, b_km, grid, st)
+                 : launch_layout<bf16_t, bf16_t, 2, true>(p, a_km, b_km, grid, st);
+  if (in_dtype == DCC_BF16 && out_dtype == DCC_F32)
+    return small ? launch_layout<bf16_t, float, 1, true>(p, a_km, b_km, grid, st)
+                 : launch_layout<bf16_t, float, 2, true>(p, a_km, b_km, grid, st);
+  if (in_dtype == DCC_F32 && out_dtype == DCC_F32)
+    return aligned ? launch_layout<float, float, 2, true>(p, a_km, b_km, grid, st)
+                   : launch_layout<float, float, 2, false>(p, a_km, b_km, grid, st);
   return DCC_ERR_UNSUPPORTED;
 }

@@ -71,8 +71,39 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
   }
 }
 
+template <typename TD, int VEC> __device__ __forceinline__ void load_vecf(const TD* p, float (&o)[VEC]) {
+  if constexpr (sizeof(TD) == 2) {
+    static_assert(VEC == 8, "bf16 rows use 8-element chunks");
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)t[e];
+  } else {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+      o[4 * q + 0] = t[0]; o[4 * q + 1] = t[1]; o[4 * q + 2] = t[2]; o[4 * q + 3] = t[3];
+    }
+  }
+}
+template <typename TD, int VEC> __device__ __forceinline__ void store_vecf(TD* p, const float (&o)[VEC]) {
+  if constexpr (sizeof(TD) == 2) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (bf16_t)o[e];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  } else {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      f32x4 t = {o[4 * q + 0], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+      *reinterpret_cast<f32x4*>(p + 4 * q) = t;
+    }
+  }
+}
+
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dgamma += dy * xhat, dbeta += dy
 // TD = element type of dy / dx (may be fp32 while x is bf16, e.g. gradients reduced with atomics).
+// Parameter gradients: registers over the row loop -> LDS per block -> ONE global atomic per column per block
+// (a few hundred blocks), instead of per-wave global atomics that serialise on C addresses.
 template <typename T, typename TD, int LPR, int ITERS>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const T* __restrict__ x,
                                                      int64_t ldx, const float* __restrict__ mean,
@@ -82,6 +113,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
   constexpr int VEC = Vec16<T>::N;
   constexpr int RPW = 64 / LPR;
   using V = vec16_t<T>;
+  extern __shared__ float red[];  // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.0f;
+  __syncthreads();
   const int lane = threadIdx.x & 63, sub = lane % LPR, rw = lane / LPR;
   const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -108,15 +142,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
       const int c = it * LPR + sub;
       if (rok && c < nch) {
         const V tx = *reinterpret_cast<const V*>(x + row * ldx + c * VEC);
+        float d[VEC];
+        load_vecf<TD, VEC>(dy + row * lddy + c * VEC, d);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          const float d = to_f32(dy[row * lddy + c * VEC + e]);
           xh[it][e] = (to_f32(tx[e]) - mu) * rs;
-          g[it][e] = d * gam[it][e];
+          g[it][e] = d[e] * gam[it][e];
           s1 += g[it][e];
           s2 += g[it][e] * xh[it][e];
-          dg[it][e] += d * xh[it][e];
-          db[it][e] += d;
+          dg[it][e] += d[e] * xh[it][e];
+          db[it][e] += d[e];
         }
       } else {
 #pragma unroll
@@ -131,14 +166,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
       for (int it = 0; it < ITERS; ++it) {
         const int c = it * LPR + sub;
         if (c < nch) {
+          float o[VEC];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e)
-            dx[row * lddx + c * VEC + e] = from_f32<TD>(rs * (g[it][e] - s1 - xh[it][e] * s2));
+          for (int e = 0; e < VEC; ++e) o[e] = rs * (g[it][e] - s1 - xh[it][e] * s2);
+          store_vecf<TD, VEC>(dx + row * lddx + c * VEC, o);
         }
       }
     }
   }
-  // fold the wave's row groups together, then one atomic per column per wave
+  // fold the wave's row groups together, then LDS across the block's waves, then one atomic per column
 #pragma unroll
   for (int it = 0; it < ITERS; ++it)
 #pragma unroll
@@ -156,11 +192,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
       if (c < nch) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          if (dgamma) atomicAdd(dgamma + c * VEC + e, dg[it][e]);
-          if (dbeta) atomicAdd(dbeta + c * VEC + e, db[it][e]);
+          atomicAdd(&red[c * VEC + e], dg[it][e]);
+          atomicAdd(&red[C + c * VEC + e], db[it][e]);
         }
       }
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    if (dgamma) atomicAdd(dgamma + i, red[i]);
+    if (dbeta) atomicAdd(dbeta + i, red[C + i]);
   }
 }
 
@@ -202,7 +243,7 @@ int ln_bwd_t(const void* dy, int64_t lddy, const void* x, int64_t ldx, const flo
   int lpr, iters;
   if (pick(C / Vec16<T>::N, lpr, iters)) return DCC_ERR_UNSUPPORTED;
   const TD* dyp = (const TD*)dy; const T* xp = (const T*)x; TD* dxp = (TD*)dx;
-#define LN_B(LP, IT) hipLaunchKernelGGL((ln_bwd_kernel<T, TD, LP, IT>), dim3(grid_for(rows, 64 / LP) > 1024 ? 1024 : grid_for(rows, 64 / LP)), dim3(256), 0, st, dyp, lddy, xp, ldx, mean, rstd, g, dxp, lddx, dgamma, dbeta, rows, C)
+#define LN_B(LP, IT) hipLaunchKernelGGL((ln_bwd_kernel<T, TD, LP, IT>), dim3(grid_for(rows, 64 / LP) > 512 ? 512 : grid_for(rows, 64 / LP)), dim3(256), 2 * C * sizeof(float), st, dyp, lddy, xp, ldx, mean, rstd, g, dxp, lddx, dgamma, dbeta, rows, C)
   if (lpr == 16) LN_B(16, 1);
   else if (lpr == 32) LN_B(32, 1);
   else if (iters == 1) LN_B(64, 1);
@@ -234,6 +275,8 @@ extern "C" int dcc_layernorm_bwd(const void* dy, int64_t lddy, const void* x, in
   if (!dy || !x || !mean || !rstd || !gamma || !dx || rows <= 0 || C <= 0) return DCC_ERR_ARG;
   const int vec = dtype == DCC_BF16 ? 8 : 4;
   if ((C % vec) || (ldx % vec) || ((uintptr_t)x & 15)) return DCC_ERR_UNSUPPORTED;
+  const int gvec = grad_dtype == DCC_BF16 ? 8 : 4;
+  if ((lddy % gvec) || (lddx % gvec) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DCC_BF16 && grad_dtype == DCC_BF16)
     return ln_bwd_t<bf16_t, bf16_t>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, st);

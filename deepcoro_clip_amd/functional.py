@@ -83,10 +83,13 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = K.gemm(g, wc, b_km=True).reshape(ctx.xshape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
+            if want_db:  # bias gradient rides in the weight-gradient GEMM (column sums of its k-major A operand)
+                db = torch.zeros(N, device=g.device, dtype=torch.float32)
             dw = K.gemm(g, x2, a_km=True, b_km=True, out_dtype=torch.float32,
-                        splitk=K.wgrad_splitk(g.shape[0], N, x2.shape[1]))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+                        splitk=K.wgrad_splitk(g.shape[0], N, x2.shape[1]), colsum=db)
+        elif want_db:
             db = K.colsum(g)
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = dy
@@ -122,15 +125,19 @@ class MlpFn(torch.autograd.Function):
         dy2 = _c(dy).reshape(-1, N)
         rows = dy2.shape[0]
         dw2 = db2 = dw1 = db1 = dx = None
+        f32 = dict(device=dy2.device, dtype=torch.float32)
         if ctx.needs_input_grad[3]:
-            dw2 = K.gemm(dy2, act, a_km=True, b_km=True, out_dtype=torch.float32, splitk=K.wgrad_splitk(rows, N, Hd))
-        if ctx.needs_input_grad[4]:
+            db2 = torch.zeros(N, **f32) if ctx.needs_input_grad[4] else None
+            dw2 = K.gemm(dy2, act, a_km=True, b_km=True, out_dtype=torch.float32, splitk=K.wgrad_splitk(rows, N, Hd),
+                         colsum=db2)
+        elif ctx.needs_input_grad[4]:
             db2 = K.colsum(dy2)
         dpre = K.gemm(dy2, w2c, b_km=True, dgelu=True, aux=pre)
         if ctx.needs_input_grad[1]:
+            db1 = torch.zeros(Hd, **f32) if ctx.needs_input_grad[2] else None
             dw1 = K.gemm(dpre, x2, a_km=True, b_km=True, out_dtype=torch.float32,
-                         splitk=K.wgrad_splitk(rows, Hd, x2.shape[1]))
-        if ctx.needs_input_grad[2]:
+                         splitk=K.wgrad_splitk(rows, Hd, x2.shape[1]), colsum=db1)
+        elif ctx.needs_input_grad[2]:
             db1 = K.colsum(dpre)
         if ctx.needs_input_grad[0]:
             dx = K.gemm(dpre, w1c, b_km=True).reshape(ctx.xshape)
@@ -157,10 +164,9 @@ class LayerNormFn(torch.autograd.Function):
         x2, mean, rstd, gamma = ctx.saved_tensors
         C = x2.shape[1]
         dy2 = _as_dtype(_c(dy).reshape(-1, C), x2.dtype)
-        dg = torch.zeros(C, device=x2.device, dtype=torch.float32)
-        db = torch.zeros(C, device=x2.device, dtype=torch.float32)
-        dx = K.layernorm_bwd(dy2, x2, mean, rstd, gamma, dg, db)
-        return dx.reshape(ctx.xshape), dg, db, None
+        dgb = torch.zeros((2, C), device=x2.device, dtype=torch.float32)  # one fill for both parameter gradients
+        dx = K.layernorm_bwd(dy2, x2, mean, rstd, gamma, dgb[0], dgb[1])
+        return dx.reshape(ctx.xshape), dgb[0], dgb[1], None
 
 
 def layernorm(x, gamma, beta, eps: float):
@@ -239,22 +245,31 @@ class MvitAttnCoreFn(torch.autograd.Function):
             K.rope(Qf[..., :D], Qf[..., :D], rope["cos_q"], rope["sin_q"])
             K.rope(Kf[..., :D], Kf[..., :D], rope["cos_k"], rope["sin_k"])
         scale = cfg["scale"]
-        idx = cfg["idx"]
-        rel = (rel_h.detach(), rel_w.detach(), rel_t.detach())
-        dims_q = K.relpos_dims(B, H, D, A, q_thw, k_thw)
-        K.relpos_tab_fwd(Qf, rel, idx, dims_q, scale)
+        idx, inv = cfg["idx"], cfg["inv"]
+        # rel-pos inner products: ONE GEMM of the (rotated) queries against the three tables stacked
+        lens = (rel_h.shape[0], rel_w.shape[0], rel_t.shape[0])
+        Lp = 8 * ((sum(lens) + 7) // 8)
+        Rcat = torch.zeros((Lp, D), device=qkv.device, dtype=dt)
+        o = 0
+        for r in (rel_h, rel_w, rel_t):
+            K.cast(r.detach().contiguous(), dt, out=Rcat[o:o + r.shape[0]])
+            o += r.shape[0]
+        q2d = Qf.view(-1, DQK)[:, :D]
+        P = K.gemm(q2d, Rcat)
+        dims_q = K.relpos_dims(B, H, D, A, Lp, q_thw, k_thw, lens)
+        K.relpos_gather(Qf, P, idx, dims_q, scale)
+        del P
         K.relpos_kaug(Kf, dims_q)
         residual = rope is None
         O, lse = K.attn_fwd(Qf, Kf, Vn, scale=scale, residual=residual, res_start=1)
         ctx.save_for_backward(qkv, conv["q"], conv["k"], conv["v"], mq, rq, mk, rk, mv, rv, Qf, Kf, Vn, O, lse,
-                              wq.detach(), wk.detach(), wv.detach(), gq.detach(), gk.detach(), gv.detach(), *rel)
-        ctx.cfg, ctx.geo, ctx.A, ctx.residual = cfg, geo, A, residual
+                              wq.detach(), wk.detach(), wv.detach(), gq.detach(), gk.detach(), gv.detach(), Rcat)
+        ctx.cfg, ctx.geo, ctx.A, ctx.residual, ctx.lens, ctx.Lp = cfg, geo, A, residual, lens, Lp
         return O.view(B * Nq, H * D)
 
     @staticmethod
     def backward(ctx, dO):
-        (qkv, cq, ck, cv, mq, rq, mk, rk, mv, rv, Qf, Kf, Vn, O, lse, wq, wk, wv, gq, gk, gv, rel_h, rel_w,
-         rel_t) = ctx.saved_tensors
+        (qkv, cq, ck, cv, mq, rq, mk, rk, mv, rv, Qf, Kf, Vn, O, lse, wq, wk, wv, gq, gk, gv, Rcat) = ctx.saved_tensors
         cfg, geo, A = ctx.cfg, ctx.geo, ctx.A
         B, N, H, D = cfg["B"], cfg["N"], cfg["H"], cfg["D"]
         dt = qkv.dtype
@@ -264,13 +279,19 @@ class MvitAttnCoreFn(torch.autograd.Function):
         scale = cfg["scale"]
         dO4 = _c(dO).view(B, Nq, H, D)
         dQf, dKf, dVn = K.attn_bwd(Qf, Kf, Vn, O, dO4, lse, scale=scale, residual=ctx.residual, res_start=1)
-        # queries: attention path + residual shortcut + table path, and the table gradients
-        dq = torch.empty((B, Nq, H, D), device=dev, dtype=dt)
+        # queries: dQf[:, :D] already holds attention path + residual shortcut; the table path goes through
+        # dP (scatter of the augmentation columns), then two GEMMs: d tables = dP^T q, dq = dP Rcat + dQf[:, :D]
         f32 = dict(device=dev, dtype=torch.float32)
-        drel = (torch.zeros(rel_h.shape, **f32), torch.zeros(rel_w.shape, **f32), torch.zeros(rel_t.shape, **f32))
-        dims_q = K.relpos_dims(B, H, D, A, geo["q"].out_thw, geo["k"].out_thw)
-        K.relpos_tab_bwd(Qf, dQf, dO4 if ctx.residual else None, dq, (rel_h, rel_w, rel_t), drel, cfg["idx"], dims_q,
-                         scale)
+        lens, Lp = ctx.lens, ctx.Lp
+        dims_q = K.relpos_dims(B, H, D, A, Lp, geo["q"].out_thw, geo["k"].out_thw, lens)
+        rows_q = B * Nq * H
+        dP = torch.empty((rows_q, Lp), device=dev, dtype=dt)
+        K.relpos_scatter(dQf, dP, cfg["inv"], dims_q, scale)
+        q2d = Qf.view(-1, DQK)[:, :D]
+        drel_cat = K.gemm(dP, q2d, a_km=True, b_km=True, out_dtype=torch.float32, splitk=K.wgrad_splitk(rows_q, Lp, D))
+        drel = (drel_cat[:lens[0]], drel_cat[lens[0]:lens[0] + lens[1]], drel_cat[lens[0] + lens[1]:sum(lens)])
+        dq = K.gemm(dP, Rcat, b_km=True, resid=dQf.view(-1, DQK)[:, :D]).view(B, Nq, H, D)
+        del dP
         dk = dKf[..., :D]  # the one-hot columns are constants
         rope = cfg.get("rope")
         if rope is not None:
@@ -280,6 +301,8 @@ class MvitAttnCoreFn(torch.autograd.Function):
             dk = dk_d
         dqkv = torch.empty((B, N, 3, H, D), device=dev, dtype=dt)
         grads = {}
+        small = torch.zeros((3, 2, D), **f32)  # LayerNorm gamma/beta gradients of the q, k, v pools (one fill)
+        small_w = torch.zeros((3, D, 27), **f32)
         for name, i, dy4, conv, mean, rstd, gam, w in (("q", 0, dq, cq, mq, rq, gq, wq), ("k", 1, dk, ck, mk, rk, gk, wk),
                                                          ("v", 2, dVn, cv, mv, rv, gv, wv)):
             g = geo[name]
@@ -288,12 +311,11 @@ class MvitAttnCoreFn(torch.autograd.Function):
                 dy2 = dy4.view(rows, D)
             else:  # dk is a column slice of the [.., DQK] buffer: rows are strided by DQK
                 dy2 = dy4.as_strided((rows, D), (dy4.stride(2), 1), dy4.storage_offset())
-            dgam = torch.zeros(D, **f32)
-            dbet = torch.zeros(D, **f32)
+            dgam, dbet = small[i, 0], small[i, 1]
             dconv = K.layernorm_bwd(dy2, conv.view(rows, D), mean, rstd, gam, dgam, dbet)
             dconv4 = dconv.view(B, g.n_out, H, D)
             K.pool_bwd_data(dconv4, dqkv[:, :, i], g, w.reshape(D, 27))
-            dw = torch.zeros((D, 27), **f32)
+            dw = small_w[i]
             K.dwconv_bwd_weight(dconv4, qkv.view(B, N, 3, H, D)[:, :, i], g, dw)
             grads[name] = (dw.view(D, 1, 3, 3, 3), dgam, dbet)
         return (dqkv.view(B * N, 3 * H * D), grads["q"][0], grads["k"][0], grads["v"][0], grads["q"][1], grads["q"][2],

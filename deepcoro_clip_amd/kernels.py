@@ -12,7 +12,7 @@ import torch
 
 from . import _lib as L
 
-GEMM_BIAS, GEMM_GELU, GEMM_SAVE_PRE, GEMM_RESID, GEMM_DGELU, GEMM_ACCUM = 1, 2, 4, 8, 16, 32
+GEMM_BIAS, GEMM_GELU, GEMM_SAVE_PRE, GEMM_RESID, GEMM_DGELU, GEMM_ACCUM, GEMM_COLSUM_A = 1, 2, 4, 8, 16, 32, 64
 
 
 class KernelTimer:
@@ -23,22 +23,34 @@ class KernelTimer:
     def __init__(self):
         self.records: dict[str, list] = {}
 
-    def time(self, family: str, units: float):
-        return _TimerCtx(self, family, units)
+    def time(self, family: str, units: float, label: str = ""):
+        return _TimerCtx(self, family, units, label)
+
+    def by_label(self) -> list:
+        """[(family, label, launches, ms, units)] sorted by time (call after summary(), which synchronises)."""
+        agg: dict = {}
+        for fam, recs in self.records.items():
+            for a, b, u, lab in recs:
+                k = (fam, lab)
+                c = agg.setdefault(k, [0, 0.0, 0.0])
+                c[0] += 1
+                c[1] += a.elapsed_time(b)
+                c[2] += u
+        return sorted(((f, l, c[0], c[1], c[2]) for (f, l), c in agg.items()), key=lambda r: -r[3])
 
     def summary(self) -> dict:
         torch.cuda.synchronize()
         out = {}
         for fam, recs in self.records.items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-            units = sum(u for _, _, u in recs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            units = sum(r[2] for r in recs)
             out[fam] = {"launches": len(recs), "ms": ms, "units": units}
         return out
 
 
 class _TimerCtx:
-    def __init__(self, timer, family, units):
-        self.t, self.f, self.u = timer, family, units
+    def __init__(self, timer, family, units, label=""):
+        self.t, self.f, self.u, self.l = timer, family, units, label
 
     def __enter__(self):
         self.a = torch.cuda.Event(enable_timing=True)
@@ -47,7 +59,7 @@ class _TimerCtx:
 
     def __exit__(self, *exc):
         self.b.record()
-        self.t.records.setdefault(self.f, []).append((self.a, self.b, self.u))
+        self.t.records.setdefault(self.f, []).append((self.a, self.b, self.u, self.l))
 
 
 TIMER: KernelTimer | None = None  # set by bench.py for the instrumented pass only
@@ -64,8 +76,8 @@ class _NoCtx:
 _NOCTX = _NoCtx()
 
 
-def _timed(family: str, units: float):
-    return TIMER.time(family, units) if TIMER is not None else _NOCTX
+def _timed(family: str, units: float, label: str = ""):
+    return TIMER.time(family, units, label) if TIMER is not None else _NOCTX
 
 
 def _i64(vals):
@@ -80,8 +92,10 @@ def _i32(vals):
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = False, bias: torch.Tensor | None = None,
          resid: torch.Tensor | None = None, aux: torch.Tensor | None = None, gelu: bool = False,
          save_pre: bool = False, dgelu: bool = False, out: torch.Tensor | None = None, accumulate: bool = False,
-         out_dtype: torch.dtype | None = None, splitk: int = 1, alpha: float = 1.0) -> torch.Tensor:
-    """C[m,n] = alpha * sum_k A(m,k) B(n,k) with fused epilogue.
+         out_dtype: torch.dtype | None = None, splitk: int = 1, alpha: float = 1.0,
+         colsum: torch.Tensor | None = None) -> torch.Tensor:
+    """C[m,n] = alpha * sum_k A(m,k) B(n,k) with fused epilogue.  `colsum` (fp32 [M], accumulated into; a_km only)
+    receives sum_k A(m,k) — the bias gradient of a Linear layer for free inside its weight-gradient GEMM.
 
     a: [M,K] (or [K,M] if a_km); b: [N,K] (or [K,N] if b_km); 2-D, inner stride 1.
     """
@@ -115,9 +129,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
         flags |= GEMM_RESID
     if accumulate:
         flags |= GEMM_ACCUM
-    with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K):
-        L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), L.ptr(resid), L.ptr(aux), a.stride(0),
-               b.stride(0), out.stride(0), resid.stride(0) if resid is not None else 0,
+    if colsum is not None:
+        assert a_km and colsum.dtype == torch.float32 and colsum.numel() == M
+        flags |= GEMM_COLSUM_A
+    with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K,
+                f"M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk} f{flags} out{out.dtype}"):
+        L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), L.ptr(resid), L.ptr(aux), L.ptr(colsum),
+               a.stride(0), b.stride(0), out.stride(0), resid.stride(0) if resid is not None else 0,
                aux.stride(0) if aux is not None else 0, M, N, K, 1, 0, 0, 0, splitk, float(alpha), flags, int(a_km),
                int(b_km), L.dt(a), L.dt(out), L.stream())
     return out
@@ -128,8 +146,9 @@ def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=N
     """Raw batched form (base tensors + explicit strides); `a`/`b`/`out` only provide base pointers and dtypes."""
     L.require_cuda(a, b, out, bias)
     flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_ACCUM if accumulate else 0)
-    with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * batch):
-        L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), None, None, lda, ldb, ldc, 0, 0, M, N, K, batch,
+    with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * batch,
+                f"batched{batch} M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk}"):
+        L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), None, None, None, lda, ldb, ldc, 0, 0, M, N, K, batch,
                sA, sB, sC, splitk, float(alpha), flags, int(a_km), int(b_km), L.dt(a), L.dt(out), L.stream())
     return out
 
@@ -160,7 +179,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: float,
     if kbias is not None:
         assert kbias.shape == (B, Nk) and kbias.dtype == torch.float32 and kbias.is_contiguous()
     st = _i64(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o))
-    with _timed("attn_fwd", 2.0 * B * H * Nq * Nk * (DQK + DV)):
+    with _timed("attn_fwd", 2.0 * B * H * Nq * Nk * (DQK + DV), f"B{B} H{H} Nq{Nq} Nk{Nk} D{DQK}/{DV}"):
         L.call("dcc_attn_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(kbias),
                L.ptr(q) if residual else None, int(res_start), st, B, H, Nq, Nk, DQK, DV, float(scale), L.dt(q),
                L.stream())
@@ -169,7 +188,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: float,
 
 def attn_bwd(q, k, v, o, do, lse, *, scale: float, kbias=None, residual: bool = False, res_start: int = 0,
              qsplit: int | None = None):
-    """Gradients of attn_fwd w.r.t. q (attention path only; the residual's dq = do is the caller's), k, v.
+    """Gradients of attn_fwd w.r.t. q (including the residual shortcut's dO when `residual`), k, v.
 
     dk/dv come back in fp32 when the query range is split (atomic accumulation)."""
     L.require_cuda(q, k, v, o, do, lse)
@@ -177,8 +196,9 @@ def attn_bwd(q, k, v, o, do, lse, *, scale: float, kbias=None, residual: bool = 
     Nk, DV = k.shape[1], v.shape[3]
     assert do.shape == o.shape and do.stride() == o.stride(), "dO must share O's layout"
     if qsplit is None:
+        # one block per CU (register-bound kernel): split the query range only as far as needed to fill 256 CUs
         kblocks = ((Nk + 127) // 128) * H * B
-        qsplit = 1 if kblocks >= 512 else max(1, min((Nq + 63) // 64, (1024 + kblocks - 1) // kblocks))
+        qsplit = 1 if kblocks >= 192 else max(1, min((Nq + 127) // 128, (512 + kblocks - 1) // kblocks))
     dq = torch.empty((B, Nq, H, DQK), device=q.device, dtype=q.dtype)
     kv_dtype = torch.float32 if qsplit > 1 else q.dtype
     alloc = torch.zeros if qsplit > 1 else torch.empty
@@ -187,7 +207,7 @@ def attn_bwd(q, k, v, o, do, lse, *, scale: float, kbias=None, residual: bool = 
     dvec = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
     st = _i64(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o) + _strides3(dq) + _strides3(dk) + _strides3(dv))
     # dQ kernel: S, dP, dQ products; dK/dV kernel: S, dP, dV, dK products
-    with _timed("attn_bwd", 2.0 * B * H * Nq * Nk * (3 * DQK + 4 * DV)):
+    with _timed("attn_bwd", 2.0 * B * H * Nq * Nk * (3 * DQK + 4 * DV), f"B{B} H{H} Nq{Nq} Nk{Nk} D{DQK}/{DV} qs{qsplit}"):
         L.call("dcc_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(dvec),
                L.ptr(kbias), L.ptr(q) if residual else None, int(res_start), L.ptr(dq), L.ptr(dk), L.ptr(dv), st, B, H,
                Nq, Nk, DQK, DV, float(scale), int(qsplit), L.dt(q), L.stream())
@@ -287,12 +307,20 @@ def pool_bwd_data(dy: torch.Tensor, dx: torch.Tensor, g: PoolGeom, weight: torch
     return dx
 
 
+_DWCONV_WS: dict = {}
+
+
 def dwconv_bwd_weight(dy: torch.Tensor, x: torch.Tensor, g: PoolGeom, dw: torch.Tensor):
-    """dw fp32 [C, taps] accumulated into."""
+    """dw fp32 [C, taps] accumulated into (per-block partials go through a cached scratch buffer, no atomics)."""
     L.require_cuda(dy, x, dw)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
-    L.call("dcc_dwconv_bwd_weight", L.ptr(dy), L.ptr(x), L.ptr(dw), g.dims(), _pool_strides(x, dy), L.dt(x), L.dt(dy),
-           L.stream())
+    n = 256 * g.C * g.kernel[0] * g.kernel[1] * g.kernel[2]  # DCC_DWCONV_WS_BLOCKS x taps x C
+    key = (str(dy.device), n)
+    ws = _DWCONV_WS.get(key)
+    if ws is None:
+        ws = _DWCONV_WS[key] = torch.empty(n, device=dy.device, dtype=torch.float32)
+    L.call("dcc_dwconv_bwd_weight", L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(ws), g.dims(), _pool_strides(x, dy), L.dt(x),
+           L.dt(dy), L.stream())
     return dw
 
 
@@ -309,27 +337,27 @@ def im2col3d(video: torch.Tensor, kernel, stride, padding, kp: int, dtype: torch
 
 
 # ------------------------------------------------------------------------------------- rel-pos
-def relpos_dims(B, H, D, A, q_thw, k_thw, has_cls=True):
-    return _i32([B, H, D, A, *q_thw, *k_thw, int(has_cls)])
+def relpos_dims(B, H, D, A, L, q_thw, k_thw, table_lens, has_cls=True):
+    return _i32([B, H, D, A, L, *q_thw, *k_thw, *table_lens, int(has_cls)])
 
 
-def relpos_tab_fwd(Qf, rel, idx, dims, scale):
-    L.require_cuda(Qf)
-    L.call("dcc_relpos_tab_fwd", L.ptr(Qf), L.ptr(rel[0]), L.ptr(rel[1]), L.ptr(rel[2]), L.ptr(idx[0]), L.ptr(idx[1]),
-           L.ptr(idx[2]), dims, _i64(_strides3(Qf)), float(scale), L.dt(Qf), L.stream())
+def relpos_gather(Qf, P, idx, dims, scale):
+    L.require_cuda(Qf, P)
+    assert P.is_contiguous() and P.dtype == Qf.dtype
+    L.call("dcc_relpos_gather", L.ptr(Qf), L.ptr(P), L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims,
+           _i64(_strides3(Qf)), float(scale), L.dt(Qf), L.stream())
+
+
+def relpos_scatter(dQf, dP, inv, dims, scale):
+    L.require_cuda(dQf, dP)
+    assert dP.is_contiguous() and dP.dtype == dQf.dtype
+    L.call("dcc_relpos_scatter", L.ptr(dQf), L.ptr(dP), L.ptr(inv[0]), L.ptr(inv[1]), L.ptr(inv[2]), dims,
+           _i64(_strides3(dQf)), float(scale), L.dt(dQf), L.stream())
 
 
 def relpos_kaug(Kf, dims):
     L.require_cuda(Kf)
     L.call("dcc_relpos_kaug", L.ptr(Kf), dims, _i64(_strides3(Kf)), L.dt(Kf), L.stream())
-
-
-def relpos_tab_bwd(Qf, dQf, dO, dq, rel, drel, idx, dims, scale):
-    L.require_cuda(Qf, dQf, dO, dq)
-    assert dQf.stride() == Qf.stride() and dq.is_contiguous()
-    L.call("dcc_relpos_tab_bwd", L.ptr(Qf), L.ptr(dQf), L.ptr(dO), _i64(_strides3(dO)) if dO is not None else None,
-           L.ptr(dq), L.ptr(rel[0]), L.ptr(rel[1]), L.ptr(rel[2]), L.ptr(drel[0]), L.ptr(drel[1]), L.ptr(drel[2]),
-           L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims, _i64(_strides3(Qf)), float(scale), L.dt(Qf), L.stream())
 
 
 # ---------------------------------------------------------------------------------- elementwise

@@ -93,10 +93,12 @@ class _Block(nn.Module):
         self._idx_cache: dict = {}
 
     def _idx(self, device):
+        """(idx, inv) device tables: idx_a[q][k] = table row of a (query coord, key coord) pair, inv_a[q][l] = the key
+        coord whose pair uses row l (or -1)."""
         key = str(device)
         if key not in self._idx_cache:
             p = self.p
-            idx = []
+            idx, inv = [], []
             for a, table in ((1, self.attn.rel_pos_h), (2, self.attn.rel_pos_w), (0, self.attn.rel_pos_t)):
                 qs, ks = p["q_thw"][a], p["k_thw"][a]
                 if table.shape[0] != 2 * max(qs, ks) - 1:
@@ -104,8 +106,12 @@ class _Block(nn.Module):
                         "relative-position table interpolation (input size not a multiple of 32 / odd frame pairs) "
                         f"is not implemented on the HIP path yet: block {p['index']} table {table.shape[0]} vs "
                         f"grid q={qs} k={ks}")
-                idx.append(Fn.relpos_index(qs, ks).to(device))
-            self._idx_cache[key] = tuple(idx)
+                ix = Fn.relpos_index(qs, ks)
+                iv = torch.full((qs, table.shape[0]), -1, dtype=torch.int32)
+                iv.scatter_(1, ix.long(), torch.arange(ks, dtype=torch.int32).expand(qs, ks).contiguous())
+                idx.append(ix.to(device))
+                inv.append(iv.contiguous().to(device))
+            self._idx_cache[key] = (tuple(idx), tuple(inv))
         return self._idx_cache[key]
 
     def forward_tokens(self, x, Bp, rope=None):
@@ -116,7 +122,8 @@ class _Block(nn.Module):
         xn1 = Fn.layernorm(x, self.norm1.weight, self.norm1.bias, self.eps)
         qkv = Fn.linear(xn1, a.qkv.weight, a.qkv.bias)
         cfg = dict(B=Bp, N=N, H=a.num_heads, D=hd, thw=p["thw"], eps=self.eps, stride_q=p["stride_q"],
-                   stride_kv=p["stride_kv"], scale=1.0 / math.sqrt(hd), idx=self._idx(x.device), rope=rope)
+                   stride_kv=p["stride_kv"], scale=1.0 / math.sqrt(hd), idx=self._idx(x.device)[0],
+                   inv=self._idx(x.device)[1], rope=rope)
         att = Fn.mvit_attention_core(
             qkv, a.pool_q.pool.weight, a.pool_k.pool.weight, a.pool_v.pool.weight,
             a.pool_q.norm_act[0].weight, a.pool_q.norm_act[0].bias, a.pool_k.norm_act[0].weight,

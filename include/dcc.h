@@ -38,7 +38,9 @@ extern "C" {
 #define DCC_GEMM_RESID 8
 #define DCC_GEMM_DGELU 16
 #define DCC_GEMM_ACCUM 32
+#define DCC_GEMM_COLSUM_A 64 /* colsum[m] += sum_k A(m,k): bias gradient fused into the k-major weight-gradient GEMM */
 #define DCC_OPT_CHUNK 4096
+#define DCC_DWCONV_WS_BLOCKS 256 /* dcc_dwconv_bwd_weight workspace = this x taps x C floats */
 
 int dcc_version(void);
 
@@ -52,10 +54,10 @@ int dcc_version(void);
  * conv as im2col GEMM (models/video_encoder.py:237) and the similarity matmuls of the losses
  * (utils/loss/losses.py:50, utils/loss/contrastive.py:150,263).
  * batch > 1 walks sA/sB/sC; splitk > 1 or DCC_GEMM_ACCUM atomically accumulates into fp32 C. */
-int dcc_gemm(const void* A, const void* B, void* C, const float* bias, const void* R, void* aux, int64_t lda,
-             int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldaux, int M, int N, int K, int batch, int64_t sA,
-             int64_t sB, int64_t sC, int splitk, float alpha, int flags, int a_km, int b_km, int in_dtype,
-             int out_dtype, void* stream);
+int dcc_gemm(const void* A, const void* B, void* C, const float* bias, const void* R, void* aux, float* colsum,
+             int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldaux, int M, int N, int K, int batch,
+             int64_t sA, int64_t sB, int64_t sC, int splitk, float alpha, int flags, int a_km, int b_km,
+             int in_dtype, int out_dtype, void* stream);
 
 /* ---- flash attention (csrc/attention.hip) ---------------------------------------------------
  * O = softmax(scale * Qf Kf^T + kbias) V (+ Qres[q][0:DV] for q >= res_start); LSE[B,H,Nq] kept.
@@ -68,23 +70,24 @@ int dcc_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LS
                  const void* Qres, int res_start, const int64_t* strides, int B, int H, int Nq, int Nk, int DQK,
                  int DV, float scale, int dtype, void* stream);
 /* strides = 21 entries: q,k,v,o,dq,dk,dv x (b,n,h).  Dv: workspace [B,H,Nq] fp32.
- * dK/dV element type: input dtype when qsplit == 1, else fp32 pre-zeroed (atomic accumulation). */
+ * dK/dV element type: input dtype when qsplit == 1, else fp32 pre-zeroed (atomic accumulation).
+ * With Qres != NULL the residual shortcut's gradient (dO for q >= res_start) is added into dQ[:, 0:DV]. */
 int dcc_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                  float* Dv, const float* kbias, const void* Qres, int res_start, void* dQ, void* dK, void* dV,
                  const int64_t* strides, int B, int H, int Nq, int Nk, int DQK, int DV, float scale, int qsplit,
                  int dtype, void* stream);
 
 /* ---- relative-position bias as contraction (csrc/relpos.hip) -------------------------------
- * torchvision mvit._add_rel_pos (call site models/video_encoder.py:354-364).
- * dims = {B,H,D,A,qt,qh,qw,kt,kh,kw,has_cls}; strides = {b,token,head} of the [B,N,H,D+A] operand. */
-int dcc_relpos_tab_fwd(void* Qf, const float* rel_h, const float* rel_w, const float* rel_t, const int* idx_h,
-                       const int* idx_w, const int* idx_t, const int* dims, const int64_t* strides, float scale,
-                       int dtype, void* stream);
+ * torchvision mvit._add_rel_pos (call site models/video_encoder.py:354-364).  The inner products q . R are one
+ * dcc_gemm against the three tables stacked ([L, D]); these kernels move its entries into / out of the
+ * augmentation columns of the attention operands.
+ * dims = {B,H,D,A,L,qt,qh,qw,kt,kh,kw,Lh,Lw,Lt,has_cls}; strides = {b,token,head} of the [B,N,H,D+A] operand;
+ * P / dP: dense [B*N*H, L]; idx_a: int32 [q_a][k_a] table row of (coord, key coord); inv_a: int32 [q_a][L_a]. */
+int dcc_relpos_gather(void* Qf, const void* P, const int* idx_h, const int* idx_w, const int* idx_t, const int* dims,
+                      const int64_t* strides, float scale, int dtype, void* stream);
+int dcc_relpos_scatter(const void* dQf, void* dP, const int* inv_h, const int* inv_w, const int* inv_t,
+                       const int* dims, const int64_t* strides, float scale, int dtype, void* stream);
 int dcc_relpos_kaug(void* Kf, const int* dims, const int64_t* strides, int dtype, void* stream);
-int dcc_relpos_tab_bwd(const void* Qf, const void* dQf, const void* dO, const int64_t* ostrides, void* dq,
-                       const float* rel_h, const float* rel_w, const float* rel_t, float* drel_h, float* drel_w,
-                       float* drel_t, const int* idx_h, const int* idx_w, const int* idx_t, const int* dims,
-                       const int64_t* strides, float scale, int dtype, void* stream);
 
 /* ---- LayerNorm (csrc/norm.hip): nn.LayerNorm in MViT blocks / Pool.norm_act / BERT / aggregator /
  * attention pool (models/video_aggregator.py:15,24,99; models/attention_pool.py:53,94). */
@@ -106,8 +109,8 @@ int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* argmax, const 
                  int mode, int dtype, void* stream);
 int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const uint8_t* argmax, const int* dims,
                       const int64_t* strides, int mode, int dtype, int grad_dtype, void* stream);
-int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, const int* dims, const int64_t* strides,
-                          int dtype, int grad_dtype, void* stream);
+int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, float* workspace, const int* dims,
+                          const int64_t* strides, int dtype, int grad_dtype, void* stream);
 
 /* ---- streaming helpers (csrc/elementwise.hip) ---------------------------------------------- */
 int dcc_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
