@@ -207,85 +207,114 @@ __global__ __launch_bounds__(256) void pool_bwd_data_kernel(const TD* __restrict
 }
 
 // ---------------------------------------------------------------- depthwise weight gradient
-// dw[c][tap] += sum over (b, head, o) dy[o][c] * x[in(o, tap)][c].  4 channels per thread,
-// per-thread register accumulators over a grid-stride token loop, LDS fold, one atomic per block.
+// dw[c][tap] += sum over (b, head, o) dy[o][c] * x[in(o, tap)][c].
+// Work item = (output token-head, temporal tap kt): one 16-byte dy chunk against the 9 spatial taps of one input
+// frame -> 9 independent 16-byte loads in flight per thread and 72 fp32 accumulators, so 4+ blocks fit per CU
+// (the first version kept 27x4 accumulators per thread, one block per CU, and was latency-bound).
+// Thread = (slot, chunk): slot % 3 = kt stays fixed over the grid-stride loop (the stride is a multiple of 3),
+// so the per-thread sums fold into LDS red[27][C] once, then the block's partial goes to the workspace.
 template <typename T, typename TD>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const TD* __restrict__ dy, const T* __restrict__ x,
-                                                                float* __restrict__ dw, PoolGeom g) {
-  constexpr int CV = 4;
-  constexpr int MAXT = 27;
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [taps][C]
+                                                                float* __restrict__ ws, PoolGeom g) {
+  constexpr int CV = Vec16<T>::N;  // channels per thread (8 bf16 / 4 fp32): 16-byte x loads
+  using V = vec16_t<T>;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [27][C]
   const int taps = g.kt * g.kh * g.kw;
   const int cpr = g.C / CV;
-  const int slots = blockDim.x / cpr;
+  const int slots = (blockDim.x / cpr) / 3 * 3;  // items per block iteration, multiple of 3
   const int c = threadIdx.x % cpr, slot = threadIdx.x / cpr;
   for (int i = threadIdx.x; i < taps * g.C; i += blockDim.x) red[i] = 0.0f;
   __syncthreads();
-  float acc[MAXT][CV];
+  float acc[9][CV];
 #pragma unroll
-  for (int k = 0; k < MAXT; ++k)
+  for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int e = 0; e < CV; ++e) acc[k][e] = 0.0f;
   const int Ngrid = g.To * g.Ho * g.Wo;
-  const int64_t total = (int64_t)g.B * g.H * Ngrid;
-  if (slot < slots) {
+  const int64_t total = (int64_t)g.B * g.H * Ngrid * 3;  // (token-head, kt) items; kt fastest
+  const int kt = slot % 3;
+  if (slot < slots && kt < g.kt) {
     for (int64_t id = (int64_t)blockIdx.x * slots + slot; id < total; id += (int64_t)gridDim.x * slots) {
-      const int o = id % Ngrid;
-      const int hd = (id / Ngrid) % g.H;
-      const int b = id / ((int64_t)Ngrid * g.H);
+      const int64_t th = id / 3;
+      const int o = th % Ngrid;
+      const int hd = (th / Ngrid) % g.H;
+      const int b = th / ((int64_t)Ngrid * g.H);
       const int wo = o % g.Wo, ho = (o / g.Wo) % g.Ho, to = o / (g.Wo * g.Ho);
-      const TD* d = dy + b * g.syb + (int64_t)(o + g.has_cls) * g.syn + hd * g.syh + c * CV;
+      const int t = to * g.st - g.pt + kt;
+      if (t < 0 || t >= g.T) continue;
       float dv[CV];
+      {
+        const TD* d = dy + b * g.syb + (int64_t)(o + g.has_cls) * g.syn + hd * g.syh + c * CV;
 #pragma unroll
-      for (int e = 0; e < CV; ++e) dv[e] = to_f32(d[e]);
-      const T* xb = x + b * g.sxb + hd * g.sxh + c * CV;
-#pragma unroll
-      for (int kt = 0; kt < 3; ++kt) {
-        const int t = to * g.st - g.pt + kt;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int hh = ho * g.sh - g.ph + kh;
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int ww = wo * g.sw - g.pw + kw;
-            if (kt < g.kt && kh < g.kh && kw < g.kw && t >= 0 && t < g.T && hh >= 0 && hh < g.Hs && ww >= 0 &&
-                ww < g.Ws) {
-              const T* xi = xb + (int64_t)(g.has_cls + (t * g.Hs + hh) * g.Ws + ww) * g.sxn;
-#pragma unroll
-              for (int e = 0; e < CV; ++e) acc[(kt * 3 + kh) * 3 + kw][e] += dv[e] * to_f32(xi[e]);
-            }
-          }
-        }
+        for (int e = 0; e < CV; ++e) dv[e] = to_f32(d[e]);
       }
-    }
+      const T* xb = x + b * g.sxb + hd * g.sxh + c * CV;
+      V xv[9];
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hh = ho * g.sh - g.ph + kh;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          if (kt < g.kt && kh < g.kh && kw < g.kw) {
-            const int tap = (kt * g.kh + kh) * g.kw + kw;
+          const int ww = wo * g.sw - g.pw + kw;
+          const bool ok = kh < g.kh && kw < g.kw && hh >= 0 && hh < g.Hs && ww >= 0 && ww < g.Ws;
+          V v;
 #pragma unroll
-            for (int e = 0; e < CV; ++e) atomicAdd(&red[tap * g.C + c * CV + e], acc[(kt * 3 + kh) * 3 + kw][e]);
-          }
+          for (int e = 0; e < CV; ++e) v[e] = (T)0.0f;
+          if (ok) v = *reinterpret_cast<const V*>(xb + (int64_t)(g.has_cls + (t * g.Hs + hh) * g.Ws + ww) * g.sxn);
+          xv[kh * 3 + kw] = v;
         }
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < CV; ++e) acc[k][e] += dv[e] * to_f32(xv[k][e]);
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        if (kh < g.kh && kw < g.kw) {
+          const int tap = (kt * g.kh + kh) * g.kw + kw;
+#pragma unroll
+          for (int e = 0; e < CV; ++e) atomicAdd(&red[tap * g.C + c * CV + e], acc[kh * 3 + kw][e]);
+        }
+      }
   }
   __syncthreads();
   // per-block partial -> workspace (plain coalesced stores); dwconv_reduce_kernel folds the blocks.
-  // (global atomics here meant gridDim x taps x C adds onto the same 2592 addresses: contention-bound)
-  float* part = dw + (int64_t)blockIdx.x * taps * g.C;
+  float* part = ws + (int64_t)blockIdx.x * taps * g.C;
   for (int i = threadIdx.x; i < taps * g.C; i += blockDim.x) part[i] = red[i];
 }
 
-// dw[c][tap] += sum_b ws[b][tap][c]
-__global__ void dwconv_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblocks, int taps, int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= taps * C) return;
+// dw[c][tap] += sum_b ws[b][tap][c]; block = 32 outputs x 8 interleaved block-groups (coalesced 128-byte rows,
+// 8 loads in flight per thread), folded through LDS.
+__global__ __launch_bounds__(256) void dwconv_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                            int nblocks, int taps, int C) {
+  __shared__ float part[8][32];
+  const int il = threadIdx.x & 31, bg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + il;
+  const int n = taps * C;
   float acc = 0.0f;
-  for (int b = 0; b < nblocks; ++b) acc += ws[(int64_t)b * taps * C + i];
-  const int k = i / C, cc = i % C;
-  dw[cc * taps + k] += acc;
+  if (i < n) {
+    int b = bg;
+    for (; b + 56 < nblocks; b += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)(b + 8 * u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < nblocks; b += 8) acc += ws[(int64_t)b * n + i];
+  }
+  part[bg][il] = acc;
+  __syncthreads();
+  if (bg == 0 && i < n) {
+    float t = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += part[u][il];
+    const int k = i / C, cc = i % C;
+    dw[cc * taps + k] += t;
+  }
 }
 
 inline unsigned blocks_for(int64_t total, int per_block, int cap) {
@@ -387,13 +416,15 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
                                      const int64_t* strides, int dtype, int grad_dtype, void* stream) {
   if (!dy || !x || !dw || !workspace || !dims || !strides) return DCC_ERR_ARG;
   PoolGeom g = make_geom(dims, strides);
-  int rc = geom_ok(g, 4);
+  int rc = geom_ok(g, dtype == DCC_BF16 ? 8 : 4);
   if (rc) return rc;
-  if (g.C / 4 > 256) return DCC_ERR_UNSUPPORTED;
-  const int slots = 256 / (g.C / 4);
+  const int cv = dtype == DCC_BF16 ? 8 : 4;
+  if (g.C % cv || g.C / cv > 85) return DCC_ERR_UNSUPPORTED;
+  const int slots = (256 / (g.C / cv)) / 3 * 3;
+  if (slots < 3) return DCC_ERR_UNSUPPORTED;
   const int taps = g.kt * g.kh * g.kw;
-  const int64_t total = (int64_t)g.B * g.H * g.To * g.Ho * g.Wo;
-  dim3 grid(blocks_for(total, slots * 4, 256));  // <= DCC_DWCONV_WS_BLOCKS
+  const int64_t total = (int64_t)g.B * g.H * g.To * g.Ho * g.Wo * 3;
+  dim3 grid(blocks_for(total, slots * 4, 1024));  // <= DCC_DWCONV_WS_BLOCKS
   const size_t lds = (size_t)taps * g.C * 4;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DCC_BF16 && grad_dtype == DCC_BF16)
@@ -405,6 +436,6 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
   else return DCC_ERR_UNSUPPORTED;
   rc = dcc_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((taps * g.C + 255) / 256), dim3(256), 0, s, workspace, dw, (int)grid.x, taps, g.C);
+  hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((taps * g.C + 31) / 32), dim3(256), 0, s, workspace, dw, (int)grid.x, taps, g.C);
   return dcc_check_launch();
 }

@@ -42,11 +42,9 @@ namespace {
 
 constexpr int NT = 256;
 
-template <typename T> struct KTile { static constexpr int BK = sizeof(T) == 2 ? 64 : 32; };
-
-template <typename T, bool KM, int TM> struct OpTile {
+template <typename T, bool KM, int TM, int BKT> struct OpTile {
   static constexpr int ES = sizeof(T);
-  static constexpr int BK = KTile<T>::BK;
+  static constexpr int BK = BKT;
   static constexpr int W = 64 * TM;                         // tile extent in the non-reduction dimension
   static constexpr int CH = 16 / ES;                        // elements per 16-byte chunk
   static constexpr int ROWB = KM ? W * ES : BK * ES + 16;   // LDS row pitch in bytes
@@ -64,39 +62,45 @@ template <int W> __device__ __forceinline__ int swz_km(int krow) {
   else return ((krow >> 1) & 1) << 2;
 }
 
-// global -> registers. `row0` is the tile origin in the non-reduction dimension, `dim` its extent.
-template <typename T, bool KM, int TM, bool ALIGNED>
-__device__ __forceinline__ void g2r(vec16_t<T>* regs, const T* base, int64_t ld, int row0, int dim, int k0, int kend,
-                                    int tid) {
-  using OT = OpTile<T, KM, TM>;
+// global -> registers.  `base` points at the tile origin (row0 folded in), `nrem` = extent left in the
+// non-reduction dimension from there.  ALIGNED path: branch-free raw buffer loads (the descriptor's range check
+// keeps tile rows past the end of the allocation from faulting) + a select for the chunks that must read as zero;
+// straight-line loads let hipcc keep several K-tiles in flight behind counted vmcnt waits.
+template <typename T, bool KM, int TM, int BKT, bool ALIGNED>
+__device__ __forceinline__ void g2r(vec16_t<T>* regs, const T* base, __amdgpu_buffer_rsrc_t rsrc, int64_t ld, int nrem,
+                                    int k0, int kend, int tid) {
+  using OT = OpTile<T, KM, TM, BKT>;
   using V = vec16_t<T>;
 #pragma unroll
   for (int i = 0; i < OT::NCH; ++i) {
     const int id = tid + NT * i;
     const int r = id / OT::CPR, c = id % OT::CPR;
     V v;
+    if constexpr (ALIGNED) {
+      int off;
+      bool ok;
+      if (!KM) { off = (r * (int)ld + k0 + c * OT::CH) * OT::ES; ok = (r < nrem) && (k0 + c * OT::CH < kend); }
+      else { off = ((k0 + r) * (int)ld + c * OT::CH) * OT::ES; ok = (k0 + r < kend) && (c * OT::CH < nrem); }
+      (void)ok;  // the zero-select happens in r2s (at LDS-store time) so that the loads stay in flight until then
+      v = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    } else {
 #pragma unroll
-    for (int e = 0; e < OT::CH; ++e) v[e] = (T)0.0f;
-    if (!KM) {
-      const int gr = row0 + r, gk = k0 + c * OT::CH;
-      if (gr < dim && gk < kend) {
-        const T* src = base + (int64_t)gr * ld + gk;
-        if constexpr (ALIGNED) v = *reinterpret_cast<const V*>(src);
-        else {
+      for (int e = 0; e < OT::CH; ++e) v[e] = (T)0.0f;
+      if (!KM) {
+        const int gk = k0 + c * OT::CH;
+        if (r < nrem && gk < kend) {
+          const T* src = base + (int64_t)r * ld + gk;
 #pragma unroll
           for (int e = 0; e < OT::CH; ++e)
             if (gk + e < kend) v[e] = src[e];
         }
-      }
-    } else {
-      const int gk = k0 + r, gc = row0 + c * OT::CH;
-      if (gk < kend && gc < dim) {
-        const T* src = base + (int64_t)gk * ld + gc;
-        if constexpr (ALIGNED) v = *reinterpret_cast<const V*>(src);
-        else {
+      } else {
+        const int gk = k0 + r, gc = c * OT::CH;
+        if (gk < kend && gc < nrem) {
+          const T* src = base + (int64_t)gk * ld + gc;
 #pragma unroll
           for (int e = 0; e < OT::CH; ++e)
-            if (gc + e < dim) v[e] = src[e];
+            if (gc + e < nrem) v[e] = src[e];
         }
       }
     }
@@ -104,9 +108,9 @@ __device__ __forceinline__ void g2r(vec16_t<T>* regs, const T* base, int64_t ld,
   }
 }
 
-template <typename T, bool KM, int TM>
-__device__ __forceinline__ void r2s(const vec16_t<T>* regs, char* buf, int tid) {
-  using OT = OpTile<T, KM, TM>;
+template <typename T, bool KM, int TM, int BKT, bool ALIGNED>
+__device__ __forceinline__ void r2s(const vec16_t<T>* regs, char* buf, int nrem, int k0, int kend, int tid) {
+  using OT = OpTile<T, KM, TM, BKT>;
   using V = vec16_t<T>;
 #pragma unroll
   for (int i = 0; i < OT::NCH; ++i) {
@@ -115,14 +119,20 @@ __device__ __forceinline__ void r2s(const vec16_t<T>* regs, char* buf, int tid) 
     int off;
     if (KM && sizeof(T) == 2) off = r * OT::ROWB + ((c ^ swz_km<OT::W>(r)) * 16);
     else off = r * OT::ROWB + c * 16;
-    *reinterpret_cast<V*>(buf + off) = regs[i];
+    V v = regs[i];
+    if constexpr (ALIGNED) {  // chunks outside the operand read as zero (the buffer load fetched whatever was there)
+      const bool ok = KM ? ((k0 + r < kend) && (c * OT::CH < nrem)) : ((r < nrem) && (k0 + c * OT::CH < kend));
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      v = __builtin_bit_cast(V, ok ? __builtin_bit_cast(u32x4, v) : zero);
+    }
+    *reinterpret_cast<V*>(buf + off) = v;
   }
 }
 
 // fragment of K-step s (16 k) for the 32 rows/cols starting at `t0` of the tile.
-template <typename T, bool KM, int TM>
+template <typename T, bool KM, int TM, int BKT>
 __device__ __forceinline__ frag_t<T> load_frag(const char* buf, int t0, int s, int lane) {
-  using OT = OpTile<T, KM, TM>;
+  using OT = OpTile<T, KM, TM, BKT>;
   const int r = lane & 31, h = lane >> 5;
   frag_t<T> f;
   if constexpr (!KM) {
@@ -156,15 +166,15 @@ __device__ __forceinline__ frag_t<T> load_frag(const char* buf, int t0, int s, i
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <typename T, typename TC, bool A_KM, bool B_KM, int TM, bool ALIGNED>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
-  using OA = OpTile<T, A_KM, TM>;
-  using OB = OpTile<T, B_KM, TM>;
-  constexpr int BK = KTile<T>::BK;
+template <typename T, typename TC, bool A_KM, bool B_KM, int TM, int BK, bool ALIGNED>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
+  using OA = OpTile<T, A_KM, TM, BK>;
+  using OB = OpTile<T, B_KM, TM, BK>;
   constexpr int BMN = 64 * TM;
   constexpr int STAGE = OA::BYTES + OB::BYTES;
   constexpr int CPITCH = BMN + 4;                       // fp32 staging pitch of the epilogue (floats)
-  constexpr int SMEM = cmax(2 * STAGE, BMN * CPITCH * 4);
+  constexpr int CROWS = BMN / 2;                        // the epilogue stages half of the tile rows at a time
+  constexpr int SMEM = cmax(2 * STAGE, CROWS * CPITCH * 4);
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,8 +190,17 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
   const int bz = blockIdx.z / p.splitk, sk = blockIdx.z % p.splitk;
   const int m0 = tm * BMN, n0 = tn * BMN;
 
-  const T* A = reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.sA;
-  const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.sB;
+  // operand bases at the tile origin + buffer descriptors covering what is left of each allocation from there
+  const T* A = reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.sA + (A_KM ? (int64_t)m0 : (int64_t)m0 * p.lda);
+  const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.sB + (B_KM ? (int64_t)n0 : (int64_t)n0 * p.ldb);
+  const int mrem = p.M - m0, nrem = p.N - n0;
+  auto remaining = [](bool km, int64_t ld, int rem, int K) -> unsigned {
+    const int64_t elems = rem <= 0 ? 0 : (km ? (int64_t)(K - 1) * ld + rem : (int64_t)(rem - 1) * ld + K);
+    const int64_t bytes = elems * (int64_t)sizeof(T);
+    return bytes > 0xffffffffLL ? 0xffffffffu : (unsigned)bytes;
+  };
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A), 0, remaining(A_KM, p.lda, mrem, p.K), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(B), 0, remaining(B_KM, p.ldb, nrem, p.K), 0x00020000);
 
   const int ksteps = (p.K + BK - 1) / BK;
   const int per = (ksteps + p.splitk - 1) / p.splitk;
@@ -203,54 +222,62 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
 #pragma unroll
   for (int e = 0; e < OA::CH; ++e) csum[e] = 0.0f;
 
-  vec16_t<T> ra[OA::NCH], rb[OB::NCH];
-  if (nk > 0) {
-    g2r<T, A_KM, TM, ALIGNED>(ra, A, p.lda, m0, p.M, ks0 * BK, kend, tid);
-    g2r<T, B_KM, TM, ALIGNED>(rb, B, p.ldb, n0, p.N, ks0 * BK, kend, tid);
-    r2s<T, A_KM, TM>(ra, smem, tid);
-    r2s<T, B_KM, TM>(rb, smem + OA::BYTES, tid);
-    if (A_KM && do_colsum) {
+  // Two register sets = prefetch distance 2: the loads of K-tile t+2 are issued before tile t+1 is written to LDS,
+  // so every global load has ~two MFMA phases to land (hipcc emits the counted vmcnt waits for plain loads).
+  vec16_t<T> ra0[OA::NCH], rb0[OB::NCH], ra1[OA::NCH], rb1[OB::NCH];
+  auto LOAD = [&](vec16_t<T>* ra, vec16_t<T>* rb, int kt) {
+    g2r<T, A_KM, TM, BK, ALIGNED>(ra, A, rsA, p.lda, mrem, (ks0 + kt) * BK, kend, tid);
+    g2r<T, B_KM, TM, BK, ALIGNED>(rb, B, rsB, p.ldb, nrem, (ks0 + kt) * BK, kend, tid);
+  };
+  auto STORE = [&](const vec16_t<T>* ra, const vec16_t<T>* rb, int buf, int kt) {
+    r2s<T, A_KM, TM, BK, ALIGNED>(ra, smem + buf * STAGE, mrem, (ks0 + kt) * BK, kend, tid);
+    r2s<T, B_KM, TM, BK, ALIGNED>(rb, smem + buf * STAGE + OA::BYTES, nrem, (ks0 + kt) * BK, kend, tid);
+    if (A_KM && do_colsum) {  // k-major A: rows past kend / columns past M contribute nothing
 #pragma unroll
-      for (int i = 0; i < OA::NCH; ++i)
+      for (int i = 0; i < OA::NCH; ++i) {
+        const int id = tid + NT * i;
+        const int r = id / OA::CPR, c = id % OA::CPR;
+        const bool ok = ((ks0 + kt) * BK + r < kend) && (c * OA::CH < mrem);
 #pragma unroll
-        for (int e = 0; e < OA::CH; ++e) csum[e] += to_f32(ra[i][e]);
+        for (int e = 0; e < OA::CH; ++e) csum[e] += ok ? to_f32(ra[i][e]) : 0.0f;
+      }
     }
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    char* curA = smem + cur * STAGE;
-    char* curB = curA + OA::BYTES;
-    char* nxtA = smem + (cur ^ 1) * STAGE;
-    char* nxtB = nxtA + OA::BYTES;
-    const bool more = kt + 1 < nk;
-    if (more) {
-      g2r<T, A_KM, TM, ALIGNED>(ra, A, p.lda, m0, p.M, (ks0 + kt + 1) * BK, kend, tid);
-      g2r<T, B_KM, TM, ALIGNED>(rb, B, p.ldb, n0, p.N, (ks0 + kt + 1) * BK, kend, tid);
-    }
+  };
+  auto COMPUTE = [&](int buf) {
+    const char* curA = smem + buf * STAGE;
+    const char* curB = curA + OA::BYTES;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       frag_t<T> fa[TM], fb[TM];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = load_frag<T, A_KM, TM>(curA, wr * 32 * TM + 32 * i, s, lane);
+      for (int i = 0; i < TM; ++i) fa[i] = load_frag<T, A_KM, TM, BK>(curA, wr * 32 * TM + 32 * i, s, lane);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) fb[j] = load_frag<T, B_KM, TM>(curB, wc * 32 * TM + 32 * j, s, lane);
+      for (int j = 0; j < TM; ++j) fb[j] = load_frag<T, B_KM, TM, BK>(curB, wc * 32 * TM + 32 * j, s, lane);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
     }
-    if (more) {
-      r2s<T, A_KM, TM>(ra, nxtA, tid);
-      r2s<T, B_KM, TM>(rb, nxtB, tid);
-      if (A_KM && do_colsum) {
-#pragma unroll
-        for (int i = 0; i < OA::NCH; ++i)
-#pragma unroll
-          for (int e = 0; e < OA::CH; ++e) csum[e] += to_f32(ra[i][e]);
-      }
-    }
+  };
+
+  if (nk > 0) {
+    LOAD(ra0, rb0, 0);
+    STORE(ra0, rb0, 0, 0);
+    if (nk > 1) LOAD(ra0, rb0, 1);
+    if (nk > 2) LOAD(ra1, rb1, 2);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even phase: LDS buffer 0 = tile kt; set 0 = tile kt+1 (in flight); set 1 = tile kt+2 (in flight)
+    COMPUTE(0);
+    if (kt + 1 < nk) STORE(ra0, rb0, 1, kt + 1);
+    if (kt + 3 < nk) LOAD(ra0, rb0, kt + 3);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // odd phase: LDS buffer 1 = tile kt+1; set 1 = tile kt+2; set 0 = tile kt+3
+    COMPUTE(1);
+    if (kt + 2 < nk) STORE(ra1, rb1, 0, kt + 2);
+    if (kt + 4 < nk) LOAD(ra1, rb1, kt + 4);
     __syncthreads();
   }
 
@@ -291,99 +318,122 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     return;
   }
 
-  // stage the fp32 tile in LDS (the K loop's last barrier has retired all fragment reads), then walk it row-major
+  // stage the fp32 tile through LDS one half (wave row wr) at a time (the K loop's last barrier has retired all
+  // fragment reads), then walk it row-major in 16-byte chunks of complete rows
   float* ct = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        ct[(wr * 32 * TM + 32 * i + acc_row(e, h)) * CPITCH + wc * 32 * TM + 32 * j + (lane & 31)] = acc[i][j][e];
-  __syncthreads();
   constexpr int GPR = BMN / 8;  // 8-column groups per tile row
   const TC* R = reinterpret_cast<const TC*>(p.R);
-  for (int gidx = tid; gidx < BMN * GPR; gidx += NT) {
-    const int r = gidx / GPR, cg = gidx % GPR;
-    const int row = m0 + r, col = n0 + cg * 8;
-    if (row >= p.M || col >= p.N) continue;
-    float v[8];
-    {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(ct + r * CPITCH + cg * 8);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + r * CPITCH + cg * 8 + 4);
-      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    }
-    const bool full = ALIGNED && (col + 8 <= p.N);
+  // a thread keeps the same 8-column group for all its rows (NT is a multiple of GPR): fetch its bias once
+  float bias8[8];
+  {
+    const int col = n0 + (tid % GPR) * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      v[e] *= p.alpha;
-      if ((p.flags & GEMM_BIAS) && col + e < p.N) v[e] += p.bias[col + e];
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.0f;
+    if (p.flags & GEMM_BIAS) {
+      if (ALIGNED && col + 8 <= p.N) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p.bias + col);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+        bias8[0] = lo[0]; bias8[1] = lo[1]; bias8[2] = lo[2]; bias8[3] = lo[3];
+        bias8[4] = hi[0]; bias8[5] = hi[1]; bias8[6] = hi[2]; bias8[7] = hi[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (col + e < p.N) bias8[e] = p.bias[col + e];
+      }
     }
-    if (p.flags & GEMM_SAVE_PRE) {
-      TC* ap = reinterpret_cast<TC*>(p.aux) + (int64_t)row * p.ldaux + col;
+  }
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
+    if (wr == half) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            ct[(32 * i + acc_row(e, h)) * CPITCH + wc * 32 * TM + 32 * j + (lane & 31)] = acc[i][j][e];
+    }
+    __syncthreads();
+    for (int gidx = tid; gidx < CROWS * GPR; gidx += NT) {
+      const int r = gidx / GPR, cg = gidx % GPR;
+      const int row = m0 + half * CROWS + r, col = n0 + cg * 8;
+      if (row >= p.M || col >= p.N) continue;
+      float v[8];
+      {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(ct + r * CPITCH + cg * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + r * CPITCH + cg * 8 + 4);
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+      }
+      const bool full = ALIGNED && (col + 8 <= p.N);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias8[e];
+      if (p.flags & GEMM_SAVE_PRE) {
+        TC* ap = reinterpret_cast<TC*>(p.aux) + (int64_t)row * p.ldaux + col;
+        if (full && sizeof(TC) == 2) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x8*>(ap) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (col + e < p.N) ap[e] = from_f32<TC>(v[e]);
+        }
+      }
+      if (p.flags & GEMM_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      }
+      if (p.flags & GEMM_DGELU) {
+        const T* ap = reinterpret_cast<const T*>(p.aux) + (int64_t)row * p.ldaux + col;
+        if (full && sizeof(T) == 2) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)a[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (col + e < p.N) v[e] *= dgelu_f(to_f32(ap[e]));
+        }
+      }
+      if (p.flags & GEMM_RESID) {
+        const TC* rp = R + (int64_t)row * p.ldr + col;
+        if (full && sizeof(TC) == 2) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(rp);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)a[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (col + e < p.N) v[e] += to_f32(rp[e]);
+        }
+      }
+      TC* dst = C + (int64_t)row * p.ldc + col;
       if (full && sizeof(TC) == 2) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-        *reinterpret_cast<bf16x8*>(ap) = o;
+        *reinterpret_cast<bf16x8*>(dst) = o;
+      } else if (full && sizeof(TC) == 4) {
+        f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(dst) = lo;
+        *reinterpret_cast<f32x4*>(dst + 4) = hi;
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (col + e < p.N) ap[e] = from_f32<TC>(v[e]);
+          if (col + e < p.N) dst[e] = from_f32<TC>(v[e]);
       }
-    }
-    if (p.flags & GEMM_GELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-    }
-    if (p.flags & GEMM_DGELU) {
-      const T* ap = reinterpret_cast<const T*>(p.aux) + (int64_t)row * p.ldaux + col;
-      if (full && sizeof(T) == 2) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)a[e]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (col + e < p.N) v[e] *= dgelu_f(to_f32(ap[e]));
-      }
-    }
-    if (p.flags & GEMM_RESID) {
-      const TC* rp = R + (int64_t)row * p.ldr + col;
-      if (full && sizeof(TC) == 2) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(rp);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)a[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (col + e < p.N) v[e] += to_f32(rp[e]);
-      }
-    }
-    TC* dst = C + (int64_t)row * p.ldc + col;
-    if (full && sizeof(TC) == 2) {
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-      *reinterpret_cast<bf16x8*>(dst) = o;
-    } else if (full && sizeof(TC) == 4) {
-      f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
-      *reinterpret_cast<f32x4*>(dst) = lo;
-      *reinterpret_cast<f32x4*>(dst + 4) = hi;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (col + e < p.N) dst[e] = from_f32<TC>(v[e]);
     }
   }
 }
 
-template <typename T, typename TC, int TM, bool ALIGNED>
+template <typename T, typename TC, int TM, int BK, bool ALIGNED>
 int launch_layout(const GemmParams& p, int a_km, int b_km, dim3 grid, hipStream_t st) {
-  if (!a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false, TM, ALIGNED>), grid, dim3(NT), 0, st, p);
-  else if (!a_km && b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true, TM, ALIGNED>), grid, dim3(NT), 0, st, p);
-  else if (a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, true, false, TM, ALIGNED>), grid, dim3(NT), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<T, TC, true, true, TM, ALIGNED>), grid, dim3(NT), 0, st, p);
+  if (!a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false, TM, BK, ALIGNED>), grid, dim3(NT), 0, st, p);
+  else if (!a_km && b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true, TM, BK, ALIGNED>), grid, dim3(NT), 0, st, p);
+  else if (a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<T, TC, true, false, TM, BK, ALIGNED>), grid, dim3(NT), 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, TC, true, true, TM, BK, ALIGNED>), grid, dim3(NT), 0, st, p);
   return dcc_check_launch();
 }
 
@@ -407,15 +457,16 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   const int och = 8;
   if ((ldc % och) || (N % och) || (sC % och)) aligned = false;
   if ((flags & GEMM_RESID) && ((ldr % och) || ((uintptr_t)R & 15))) aligned = false;
+  if ((flags & GEMM_BIAS) && ((uintptr_t)bias & 15)) aligned = false;
   if ((flags & (GEMM_SAVE_PRE | GEMM_DGELU)) && ((ldaux % och) || ((uintptr_t)aux & 15))) aligned = false;
   if ((splitk > 1 || (flags & GEMM_ACCUM)) && out_dtype != DCC_F32) return DCC_ERR_ARG;
   if ((flags & GEMM_BIAS) && !bias) return DCC_ERR_ARG;
   if ((flags & GEMM_RESID) && !R) return DCC_ERR_ARG;
   if ((flags & (GEMM_SAVE_PRE | GEMM_DGELU)) && !aux) return DCC_ERR_ARG;
   if ((flags & GEMM_COLSUM_A) && (!colsum || !a_km || batch != 1)) return DCC_ERR_ARG;
-  if (splitk > 1 && (flags & ~(GEMM_BIAS | GEMM_ACCUM | GEMM_COLSUM_A))) return DCC_ERR_ARG;  // non-linear epilogues need the full sum
+  if (splitk > 1 && (flags & 0xff & ~(GEMM_BIAS | GEMM_ACCUM | GEMM_COLSUM_A))) return DCC_ERR_ARG;  // non-linear epilogues need the full sum
   if (!aligned && in_dtype != DCC_F32) return DCC_ERR_UNSUPPORTED;  // bf16 callers always meet the chunk rules
-  GemmParams p{A, B, C, bias, R, aux, colsum, lda, ldb, ldc, ldr, ldaux, sA, sB, sC, M, N, K, batch, splitk, alpha, flags};
+  GemmParams p{A, B, C, bias, R, aux, colsum, lda, ldb, ldc, ldr, ldaux, sA, sB, sC, M, N, K, batch, splitk, alpha, flags & 0xff};
   if ((int64_t)batch * splitk > 65535) return DCC_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   // tile choice: 128x128 unless that leaves most of the 256 CUs idle
@@ -425,14 +476,19 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   const int64_t tiles = (int64_t)((M + bmn - 1) / bmn) * ((N + bmn - 1) / bmn);
   if (tiles > 0x7fffffffLL) return DCC_ERR_ARG;
   dim3 grid((unsigned)tiles, 1, (unsigned)(batch * splitk));
-  if (in_dtype == DCC_BF16 && out_dtype == DCC_BF16)
-    return small ? launch_layout<bf16_t, bf16_t, 1, true>(p, a_km, b_km, grid, st)
-                 : launch_layout<bf16_t, bf16_t, 2, true>(p, a_km, b_km, grid, st);
-  if (in_dtype == DCC_BF16 && out_dtype == DCC_F32)
-    return small ? launch_layout<bf16_t, float, 1, true>(p, a_km, b_km, grid, st)
-                 : launch_layout<bf16_t, float, 2, true>(p, a_km, b_km, grid, st);
+  const int variant = (flags >> 8) & 0xff;  // tuning knob (bench / tests only): 1 = BK 32 for the 128-tile bf16 kernels
+  if (in_dtype == DCC_BF16 && out_dtype == DCC_BF16) {
+    if (small) return launch_layout<bf16_t, bf16_t, 1, 64, true>(p, a_km, b_km, grid, st);
+    return variant == 1 ? launch_layout<bf16_t, bf16_t, 2, 32, true>(p, a_km, b_km, grid, st)
+                        : launch_layout<bf16_t, bf16_t, 2, 64, true>(p, a_km, b_km, grid, st);
+  }
+  if (in_dtype == DCC_BF16 && out_dtype == DCC_F32) {
+    if (small) return launch_layout<bf16_t, float, 1, 64, true>(p, a_km, b_km, grid, st);
+    return variant == 1 ? launch_layout<bf16_t, float, 2, 32, true>(p, a_km, b_km, grid, st)
+                        : launch_layout<bf16_t, float, 2, 64, true>(p, a_km, b_km, grid, st);
+  }
   if (in_dtype == DCC_F32 && out_dtype == DCC_F32)
-    return aligned ? launch_layout<float, float, 2, true>(p, a_km, b_km, grid, st)
-                   : launch_layout<float, float, 2, false>(p, a_km, b_km, grid, st);
+    return aligned ? launch_layout<float, float, 2, 32, true>(p, a_km, b_km, grid, st)
+                   : launch_layout<float, float, 2, 32, false>(p, a_km, b_km, grid, st);
   return DCC_ERR_UNSUPPORTED;
 }

@@ -13,6 +13,9 @@ import torch
 from . import _lib as L
 
 GEMM_BIAS, GEMM_GELU, GEMM_SAVE_PRE, GEMM_RESID, GEMM_DGELU, GEMM_ACCUM, GEMM_COLSUM_A = 1, 2, 4, 8, 16, 32, 64
+import os as _os
+
+GEMM_VARIANT = int(_os.environ.get("DCC_GEMM_VARIANT", "0")) << 8  # tuning knob for A/B runs (see csrc/gemm.hip)
 
 
 class KernelTimer:
@@ -132,6 +135,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
     if colsum is not None:
         assert a_km and colsum.dtype == torch.float32 and colsum.numel() == M
         flags |= GEMM_COLSUM_A
+    flags |= GEMM_VARIANT
     with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K,
                 f"M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk} f{flags} out{out.dtype}"):
         L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), L.ptr(resid), L.ptr(aux), L.ptr(colsum),
@@ -145,7 +149,7 @@ def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=N
                  alpha: float = 1.0, accumulate: bool = False, splitk: int = 1):
     """Raw batched form (base tensors + explicit strides); `a`/`b`/`out` only provide base pointers and dtypes."""
     L.require_cuda(a, b, out, bias)
-    flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_ACCUM if accumulate else 0)
+    flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_ACCUM if accumulate else 0) | GEMM_VARIANT
     with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * batch,
                 f"batched{batch} M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk}"):
         L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), None, None, None, lda, ldb, ldc, 0, 0, M, N, K, batch,
@@ -314,7 +318,7 @@ def dwconv_bwd_weight(dy: torch.Tensor, x: torch.Tensor, g: PoolGeom, dw: torch.
     """dw fp32 [C, taps] accumulated into (per-block partials go through a cached scratch buffer, no atomics)."""
     L.require_cuda(dy, x, dw)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
-    n = 256 * g.C * g.kernel[0] * g.kernel[1] * g.kernel[2]  # DCC_DWCONV_WS_BLOCKS x taps x C
+    n = 1024 * g.C * g.kernel[0] * g.kernel[1] * g.kernel[2]  # DCC_DWCONV_WS_BLOCKS x taps x C
     key = (str(dy.device), n)
     ws = _DWCONV_WS.get(key)
     if ws is None:

@@ -40,7 +40,7 @@ extern "C" {
 #define DCC_GEMM_ACCUM 32
 #define DCC_GEMM_COLSUM_A 64 /* colsum[m] += sum_k A(m,k): bias gradient fused into the k-major weight-gradient GEMM */
 #define DCC_OPT_CHUNK 4096
-#define DCC_DWCONV_WS_BLOCKS 256 /* dcc_dwconv_bwd_weight workspace = this x taps x C floats */
+#define DCC_DWCONV_WS_BLOCKS 1024 /* dcc_dwconv_bwd_weight workspace = this x taps x C floats */
 
 int dcc_version(void);
 
