@@ -46,6 +46,61 @@ def wcast(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return t
 
 
+class ZeroArena:
+    """One big pre-zeroed fp32 buffer per training step for every gradient that is produced by accumulation
+    (split-K / atomics): one memset instead of ~800 small fill launches.  `begin()` re-zeroes and rewinds; slices
+    handed out stay valid until the next `begin()` (the runner calls it where the reference calls zero_grad)."""
+
+    def __init__(self):
+        self.buf: torch.Tensor | None = None
+        self.off = 0
+        self.active = False
+        self.high = 0
+
+    def begin(self, device, numel_hint: int):
+        need = max(numel_hint, self.high)
+        if self.buf is None or self.buf.device != device or self.buf.numel() < need:
+            self.buf = torch.empty(int(need * 1.05) + 4096, device=device, dtype=torch.float32)
+        self.buf.zero_()
+        self.off = 0
+        self.active = True
+
+    def end(self):
+        self.active = False
+
+    def zeros(self, shape, device) -> torch.Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n4 = (n + 3) // 4 * 4  # keep every slice 16-byte aligned
+        if self.active and self.buf is not None and self.buf.device == device and self.off + n4 <= self.buf.numel():
+            t = self.buf[self.off:self.off + n].view(shape)
+            self.off += n4
+            self.high = max(self.high, self.off)
+            return t
+        self.high = max(self.high, self.off + n4)
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+
+
+ARENA = ZeroArena()
+
+
+def zeros_f32(shape, device) -> torch.Tensor:
+    return ARENA.zeros(tuple(shape) if not isinstance(shape, int) else (shape,), device)
+
+
+def wgrad(g2: torch.Tensor, x2: torch.Tensor, colsum: torch.Tensor | None = None) -> torch.Tensor:
+    """dW[n][k] = sum_rows g2[row][n] * x2[row][k] in fp32 (k-major GEMM; split over the row range when the
+    n x k output alone cannot fill the chip, accumulating into a pre-zeroed arena slice)."""
+    rows, N = g2.shape
+    Kd = x2.shape[1]
+    sk = K.wgrad_splitk(rows, N, Kd)
+    if sk > 1:
+        return K.gemm(g2, x2, a_km=True, b_km=True, out=zeros_f32((N, Kd), g2.device), accumulate=True, splitk=sk,
+                      colsum=colsum)
+    return K.gemm(g2, x2, a_km=True, b_km=True, out_dtype=torch.float32, colsum=colsum)
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -86,9 +141,8 @@ class LinearFn(torch.autograd.Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_db:  # bias gradient rides in the weight-gradient GEMM (column sums of its k-major A operand)
-                db = torch.zeros(N, device=g.device, dtype=torch.float32)
-            dw = K.gemm(g, x2, a_km=True, b_km=True, out_dtype=torch.float32,
-                        splitk=K.wgrad_splitk(g.shape[0], N, x2.shape[1]), colsum=db)
+                db = zeros_f32(N, g.device)
+            dw = wgrad(g, x2, db)
         elif want_db:
             db = K.colsum(g)
         if ctx.has_res and ctx.needs_input_grad[4]:
@@ -127,16 +181,14 @@ class MlpFn(torch.autograd.Function):
         dw2 = db2 = dw1 = db1 = dx = None
         f32 = dict(device=dy2.device, dtype=torch.float32)
         if ctx.needs_input_grad[3]:
-            db2 = torch.zeros(N, **f32) if ctx.needs_input_grad[4] else None
-            dw2 = K.gemm(dy2, act, a_km=True, b_km=True, out_dtype=torch.float32, splitk=K.wgrad_splitk(rows, N, Hd),
-                         colsum=db2)
+            db2 = zeros_f32(N, dy2.device) if ctx.needs_input_grad[4] else None
+            dw2 = wgrad(dy2, act, db2)
         elif ctx.needs_input_grad[4]:
             db2 = K.colsum(dy2)
         dpre = K.gemm(dy2, w2c, b_km=True, dgelu=True, aux=pre)
         if ctx.needs_input_grad[1]:
-            db1 = torch.zeros(Hd, **f32) if ctx.needs_input_grad[2] else None
-            dw1 = K.gemm(dpre, x2, a_km=True, b_km=True, out_dtype=torch.float32,
-                         splitk=K.wgrad_splitk(rows, Hd, x2.shape[1]), colsum=db1)
+            db1 = zeros_f32(Hd, dy2.device) if ctx.needs_input_grad[2] else None
+            dw1 = wgrad(dpre, x2, db1)
         elif ctx.needs_input_grad[2]:
             db1 = K.colsum(dpre)
         if ctx.needs_input_grad[0]:
@@ -164,7 +216,7 @@ class LayerNormFn(torch.autograd.Function):
         x2, mean, rstd, gamma = ctx.saved_tensors
         C = x2.shape[1]
         dy2 = _as_dtype(_c(dy).reshape(-1, C), x2.dtype)
-        dgb = torch.zeros((2, C), device=x2.device, dtype=torch.float32)  # one fill for both parameter gradients
+        dgb = zeros_f32((2, C), x2.device)
         dx = K.layernorm_bwd(dy2, x2, mean, rstd, gamma, dgb[0], dgb[1])
         return dx.reshape(ctx.xshape), dgb[0], dgb[1], None
 
@@ -229,7 +281,8 @@ class MvitAttnCoreFn(torch.autograd.Function):
         for name, idx, w, stride in (("q", 0, wq, cfg["stride_q"]), ("k", 1, wk, cfg["stride_kv"]), ("v", 2, wv, cfg["stride_kv"])):
             g = K.PoolGeom(B, H, D, tuple(thw), (3, 3, 3), tuple(stride), (1, 1, 1), True)
             geo[name] = g
-            conv[name], _ = K.pool_fwd(qkv5[:, :, idx], g, w.detach().reshape(D, 27))
+            w27 = w.detach().reshape(D, 27)
+            conv[name], _ = K.pool_fwd(qkv5[:, :, idx], g, w27)
         q_thw, k_thw = geo["q"].out_thw, geo["k"].out_thw
         Nq, Nk = geo["q"].n_out, geo["k"].n_out
         A = relpos_aug_width(k_thw)
@@ -288,7 +341,7 @@ class MvitAttnCoreFn(torch.autograd.Function):
         dP = torch.empty((rows_q, Lp), device=dev, dtype=dt)
         K.relpos_scatter(dQf, dP, cfg["inv"], dims_q, scale)
         q2d = Qf.view(-1, DQK)[:, :D]
-        drel_cat = K.gemm(dP, q2d, a_km=True, b_km=True, out_dtype=torch.float32, splitk=K.wgrad_splitk(rows_q, Lp, D))
+        drel_cat = wgrad(dP, q2d)
         drel = (drel_cat[:lens[0]], drel_cat[lens[0]:lens[0] + lens[1]], drel_cat[lens[0] + lens[1]:sum(lens)])
         dq = K.gemm(dP, Rcat, b_km=True, resid=dQf.view(-1, DQK)[:, :D]).view(B, Nq, H, D)
         del dP
@@ -301,8 +354,8 @@ class MvitAttnCoreFn(torch.autograd.Function):
             dk = dk_d
         dqkv = torch.empty((B, N, 3, H, D), device=dev, dtype=dt)
         grads = {}
-        small = torch.zeros((3, 2, D), **f32)  # LayerNorm gamma/beta gradients of the q, k, v pools (one fill)
-        small_w = torch.zeros((3, D, 27), **f32)
+        small = zeros_f32((3, 2, D), dev)  # LayerNorm gamma/beta gradients of the q, k, v pools
+        small_w = zeros_f32((3, D, 27), dev)
         for name, i, dy4, conv, mean, rstd, gam, w in (("q", 0, dq, cq, mq, rq, gq, wq), ("k", 1, dk, ck, mk, rk, gk, wk),
                                                          ("v", 2, dVn, cv, mv, rv, gv, wv)):
             g = geo[name]

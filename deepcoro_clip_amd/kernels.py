@@ -158,11 +158,14 @@ def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=N
 
 
 def wgrad_splitk(rows: int, n: int, k: int) -> int:
-    """Split factor for weight-gradient GEMMs (reduction over `rows`, output n x k)."""
+    """Split factor for weight-gradient GEMMs (reduction over `rows`, output n x k).
+
+    Measured on MI355X (scratch/wgrad_sweep.py): the fp32 atomics of the split-K epilogue are served at the memory
+    side, so the fastest split is the SMALLEST one that still gives every CU a block (~160 blocks of 128x128 output
+    tiles); only outputs of a few tiles want more (their blocks are otherwise too few and too long)."""
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
-    ksteps = (rows + 31) // 32
-    want = max(1, 1024 // tiles)
-    return int(max(1, min(want, ksteps // 4 if ksteps >= 8 else 1, 512)))
+    want = round(160 / tiles) if tiles >= 4 else 384 // tiles
+    return int(max(1, min(want, rows // 128, 512)))
 
 
 # ------------------------------------------------------------------------------------ attention

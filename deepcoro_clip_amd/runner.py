@@ -87,6 +87,11 @@ class VideoContrastiveLearningRunner:
             self.optimizer.zero_grad(set_to_none=True)
         for w in wrappers:  # flat gradient arenas: zero + re-attach views (replaces set_to_none)
             w.attach_grads()
+        if int(_cfg(self.config, "gradient_accumulation_steps", 1)) == 1 and self.optimizer is not None:
+            # accumulation-produced gradients of this step come out of one pre-zeroed arena (one memset per step)
+            dev = self.log_temp.device if self.log_temp is not None else torch.device("cuda")
+            hint = sum(p.numel() for g in self.optimizer.param_groups for p in g["params"]) + (1 << 20)
+            Fn.ARENA.begin(dev, hint)
 
     def _all_encoder_params(self):
         return list(itertools.chain(self.video_encoder.parameters(), self.text_encoder.parameters()))

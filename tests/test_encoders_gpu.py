@@ -18,13 +18,14 @@ def _make_video(B, N, T, S, seed=0):
     return torch.randn(shape, generator=g)
 
 
-def _grad_check(prod, orc, names_tol, default_tol):
+def _grad_check(prod, orc, names_tol, default_tol, floor_frac=1e-2):
     """Relative Frobenius error per parameter.  Some gradients are analytically zero (a key bias / key-LayerNorm bias
-    shifts every logit of a row equally), so the denominator is floored by a fraction of the typical gradient norm."""
+    shifts every logit of a row equally), so the denominator is floored by a fraction of the typical gradient norm
+    (bf16 runs: rounding noise on such a parameter scales with the activations, not with its own tiny gradient)."""
     bad = []
     op = dict(orc.named_parameters())
     norms = sorted(float(q.grad.double().norm()) for q in op.values() if q.grad is not None)
-    floor = 1e-2 * norms[len(norms) // 2]
+    floor = floor_frac * norms[len(norms) // 2]
     for n, p in prod.named_parameters():
         if op[n].grad is None:
             assert p.grad is None or p.grad.abs().max() == 0, n
@@ -62,7 +63,7 @@ def test_video_encoder_vs_oracle(dtype, tol, gtol, pooling, N):
     g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1)).double()
     ref.backward(g)
     out.backward(g.float().cuda())
-    _grad_check(prod, orc, {"rel_pos": gtol * 4}, gtol)
+    _grad_check(prod, orc, {"rel_pos": gtol * 4}, gtol, 1e-2 if dtype == torch.float32 else 5e-2)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 5e-2)])
