@@ -1,0 +1,233 @@
+"""Bandwidth-bound HIP kernels (LayerNorm, depthwise/max pooling, patch embedding, RoPE, embeddings, token mean,
+elementwise) through the C ABI against plain PyTorch fp32 references of the same op, plus the reference-generated
+RoPE golden (tests/golden/rope.npz).  fp32: 1e-5-class; bf16: 1e-2-class (tolerances stated per test)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+def _gen(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("rows,C", [(1, 96), (393, 96), (1000, 192), (37, 384), (257, 768), (64, 512)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+def test_layernorm_fwd_bwd(rows, C, dtype, tol):
+    from deepcoro_clip_amd import functional as Fn
+
+    g = _gen(rows + C)
+    x0 = torch.randn(rows, C, generator=g) * 2 + 0.5
+    gam0, bet0, dy0 = torch.randn(C, generator=g), torch.randn(C, generator=g), torch.randn(rows, C, generator=g)
+    x0 = x0.to(dtype).float()  # both sides start from the same (rounded) activations
+    xr, gr, br = x0.clone().requires_grad_(True), gam0.clone().requires_grad_(True), bet0.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), gr, br, 1e-6)
+    yr.backward(dy0.to(dtype).float())
+    x = x0.cuda().to(dtype).requires_grad_(True)
+    gam, bet = gam0.cuda().requires_grad_(True), bet0.cuda().requires_grad_(True)
+    y = Fn.layernorm(x, gam, bet, 1e-6)
+    y.backward(dy0.cuda().to(dtype))
+    assert y.dtype == dtype and _rel(y.float(), yr) < tol
+    assert _rel(x.grad.float(), xr.grad) < tol
+    assert _rel(gam.grad, gr.grad) < tol and _rel(bet.grad, br.grad) < tol
+
+
+def test_layernorm_rejects_unsupported_width():
+    from deepcoro_clip_amd import kernels as K
+    from deepcoro_clip_amd._lib import DccError
+
+    x = torch.randn(4, 3072, device="cuda")
+    with pytest.raises(DccError):  # wider than any LayerNorm on the path (<= 768): loud, no fallback
+        K.layernorm_fwd(x, torch.ones(3072, device="cuda"), torch.zeros(3072, device="cuda"), 1e-6)
+    with pytest.raises(DccError):
+        K.layernorm_fwd(x.cpu(), torch.ones(3072), torch.zeros(3072), 1e-6)
+
+
+@pytest.mark.parametrize("stride,thw,H,C", [((1, 1, 1), (4, 8, 8), 2, 96), ((1, 2, 2), (4, 8, 8), 1, 96),
+                                            ((1, 4, 4), (2, 16, 16), 2, 96), ((1, 8, 8), (2, 16, 16), 1, 96),
+                                            ((1, 2, 2), (3, 7, 7), 4, 96), ((1, 1, 1), (2, 5, 3), 8, 96)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_depthwise_pool_fwd_bwd(stride, thw, H, C, dtype, tol):
+    """Pool's Conv3d(groups=C, k=3, p=1, stride) on [B, N, H, C] token views with class-token bypass (R4)."""
+    from deepcoro_clip_amd import kernels as K
+
+    B = 2
+    g = _gen(7)
+    geo = K.PoolGeom(B, H, C, thw, (3, 3, 3), stride, (1, 1, 1), True)
+    x0 = torch.randn(B, geo.n_in, H, C, generator=g).to(dtype).float()
+    w0 = torch.randn(C, 1, 3, 3, 3, generator=g) * 0.2
+    dy0 = torch.randn(B, geo.n_out, H, C, generator=g).to(dtype).float()
+
+    def ref(x, w):
+        cls, tok = x[:, :1], x[:, 1:]
+        t = tok.permute(0, 2, 3, 1).reshape(B * H, C, *thw)
+        o = F.conv3d(t, w, None, stride, (1, 1, 1), groups=C)
+        o = o.reshape(B, H, C, -1).permute(0, 3, 1, 2)
+        return torch.cat([cls, o], 1)
+
+    xr, wr = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    yr = ref(xr, wr)
+    yr.backward(dy0)
+    x = x0.cuda().to(dtype)
+    y, _ = K.pool_fwd(x, geo, w0.cuda().reshape(C, 27))
+    assert _rel(y.float(), yr) < tol
+    dx = torch.empty_like(x)
+    K.pool_bwd_data(dy0.cuda().to(dtype), dx, geo, w0.cuda().reshape(C, 27))
+    assert _rel(dx.float(), xr.grad) < tol
+    dw = torch.zeros(C, 27, device="cuda")
+    K.dwconv_bwd_weight(dy0.cuda().to(dtype), x, geo, dw)
+    assert _rel(dw.view_as(w0), wr.grad) < tol
+    K.dwconv_bwd_weight(dy0.cuda().to(dtype), x, geo, dw)  # accumulates
+    assert _rel(dw.view_as(w0), 2 * wr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_skip_fwd_bwd(dtype):
+    """pool_skip: MaxPool3d k(1,3,3) s(1,2,2) p(0,1,1) on the non-class tokens.  Max pooling selects, so results are
+    bit-exact in either dtype."""
+    from deepcoro_clip_amd import functional as Fn
+
+    B, C, thw = 2, 192, (2, 7, 9)
+    g = _gen(3)
+    n = thw[0] * thw[1] * thw[2] + 1
+    x0 = torch.randn(B * n, C, generator=g).to(dtype).float()
+    xr = x0.clone().requires_grad_(True)
+    tok = xr.view(B, n, C)[:, 1:].permute(0, 2, 1).reshape(B, C, *thw)
+    o = F.max_pool3d(tok, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    yr = torch.cat([xr.view(B, n, C)[:, :1], o.flatten(2).transpose(1, 2)], 1).reshape(-1, C)
+    dy0 = torch.randn(yr.shape, generator=g).to(dtype).float()
+    yr.backward(dy0)
+    x = x0.cuda().to(dtype).requires_grad_(True)
+    y = Fn.pool_skip(x, B, thw, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    y.backward(dy0.cuda().to(dtype))
+    assert torch.equal(y.float().cpu(), yr.detach())
+    assert _rel(x.grad.float(), xr.grad) < (1e-6 if dtype == torch.float32 else 1e-2)  # overlapping windows add
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("B,T,S", [(2, 4, 32), (1, 2, 20), (3, 6, 28)])
+def test_patch_embed_fwd_bwd(dtype, tol, B, T, S):
+    """conv_proj + class token as im2col + MFMA GEMM vs F.conv3d on the NDHWC video (models/video_encoder.py:237-241)."""
+    from deepcoro_clip_amd import functional as Fn
+
+    g = _gen(11)
+    v0 = torch.randn(B, T, S, S, 3, generator=g)
+    w0 = torch.randn(96, 3, 3, 7, 7, generator=g) * 0.05
+    b0, c0 = torch.randn(96, generator=g), torch.randn(96, generator=g)
+    wr, br, cr = (t.clone().requires_grad_(True) for t in (w0, b0, c0))
+    o = F.conv3d(v0.permute(0, 4, 1, 2, 3), wr, br, (2, 4, 4), (1, 3, 3)).flatten(2).transpose(1, 2)
+    yr = torch.cat([cr.expand(B, 1, 96), o], 1)
+    dy0 = torch.randn(yr.shape, generator=g)
+    yr.backward(dy0)
+    w, b, c = (t.cuda().requires_grad_(True) for t in (w0, b0, c0))
+    y = Fn.patch_embed(v0.cuda(), w, b, c, dtype)
+    assert y.shape == (B * yr.shape[1], 96)
+    y.backward(dy0.cuda().to(dtype).view(-1, 96))
+    assert _rel(y.float().view_as(yr), yr) < tol
+    assert _rel(w.grad, wr.grad) < tol and _rel(b.grad, br.grad) < tol and _rel(c.grad, cr.grad) < tol
+
+
+def test_rope_kernel_matches_reference_golden():
+    """dcc_rope with the host-built tables vs models/rope_3d.py outputs recorded in tests/golden/rope.npz
+    (a subset `tok` of the 393 tokens of an 8x7x7 grid, class token first)."""
+    from deepcoro_clip_amd import kernels as K
+    from deepcoro_clip_amd.mvit import rope_tables
+
+    d = np.load(os.path.join(G, "rope.npz"))
+    cos, sin = rope_tables(8, 7, 7, 96, n_special=1)
+    assert np.allclose(cos.numpy(), d["cos"], atol=1e-6) and np.allclose(sin.numpy(), d["sin"], atol=1e-6)
+    tok = torch.from_numpy(d["tok"]).long()
+    cos_t, sin_t = cos[tok].contiguous().cuda(), sin[tok].contiguous().cuda()
+    for name in ("q", "k"):
+        x = torch.from_numpy(d[name]).permute(0, 2, 1, 3).contiguous().cuda()  # [B, N, h, D]
+        y = torch.empty_like(x)
+        K.rope(x, y, cos_t, sin_t)
+        ref = torch.from_numpy(d[name + "_rot"]).permute(0, 2, 1, 3)
+        assert (y.cpu() - ref).abs().max().item() < 1e-5
+        back = torch.empty_like(x)
+        K.rope(y, back, cos_t, sin_t, backward=True)  # a rotation: the adjoint is the inverse
+        assert (back - x).abs().max().item() < 1e-5
+        xb = x.bfloat16()
+        yb = torch.empty_like(xb)
+        K.rope(xb, yb, cos_t, sin_t)
+        assert _rel(yb.float().cpu(), ref) < 1e-2
+    c2, s2 = rope_tables(8, 14, 14, 96, n_special=1)
+    sel = torch.from_numpy(d["sel"]).long()
+    x = torch.from_numpy(d["q2_sel"]).permute(0, 2, 1, 3).contiguous().cuda()
+    y = torch.empty_like(x)
+    K.rope(x, y, c2[sel].contiguous().cuda(), s2[sel].contiguous().cuda())
+    assert (y.cpu() - torch.from_numpy(d["q2_rot_sel"]).permute(0, 2, 1, 3)).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+def test_embedding_fwd_bwd(dtype, tol):
+    """BERT embeddings: word + position + token-type(0) sum and its scatter-add gradient."""
+    from deepcoro_clip_amd import functional as Fn
+
+    g = _gen(5)
+    V, P, D, B, S = 300, 40, 768, 3, 17
+    ids = torch.randint(0, V, (B, S), generator=g)
+    ids[0, :4] = 7  # repeated ids -> colliding atomic adds
+    w0, p0, t0 = torch.randn(V, D, generator=g), torch.randn(P, D, generator=g), torch.randn(2, D, generator=g)
+    wr, pr, tr = (t.clone().requires_grad_(True) for t in (w0, p0, t0))
+    yr = F.embedding(ids, wr) + pr[:S][None] + tr[0][None, None]
+    dy0 = torch.randn(yr.shape, generator=g).to(dtype).float()
+    yr.backward(dy0)
+    w, p, t = (x.cuda().requires_grad_(True) for x in (w0, p0, t0))
+    y = Fn.embed(ids.cuda(), w, p, t, dtype)
+    y.backward(dy0.cuda().to(dtype).view(y.shape))
+    assert _rel(y.float().view_as(yr), yr) < tol
+    assert _rel(w.grad, wr.grad) < tol and _rel(p.grad, pr.grad) < tol and _rel(t.grad, tr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+def test_token_mean_qpool_add_cast(dtype, tol):
+    from deepcoro_clip_amd import functional as Fn
+
+    g = _gen(9)
+    x0 = torch.randn(3, 393, 512, generator=g).to(dtype).float()
+    xr = x0.clone().requires_grad_(True)
+    xr.mean(1).backward(torch.ones(3, 512))
+    x = x0.cuda().to(dtype).requires_grad_(True)
+    y = Fn.token_mean(x)
+    y.backward(torch.ones(3, 512, device="cuda", dtype=dtype))
+    assert _rel(y.float(), x0.mean(1)) < tol and _rel(x.grad.float(), xr.grad) < tol
+    # aggregator pooling: softmax(q . x^T) x over the N videos of a study (unscaled, video_aggregator.py:146-158)
+    z0, q0 = torch.randn(4, 5, 512, generator=g) * 0.1, torch.randn(512, generator=g) * 0.1
+    zr, qr = z0.clone().requires_grad_(True), q0.clone().requires_grad_(True)
+    wts = torch.softmax(zr @ qr, dim=1)
+    outr = (wts[..., None] * zr).sum(1)
+    go = torch.randn(4, 512, generator=g)
+    outr.backward(go)
+    z, q = z0.cuda().requires_grad_(True), q0.cuda().requires_grad_(True)
+    out = Fn.qpool(z, q)
+    out.backward(go.cuda())
+    assert _rel(out, outr) < 1e-5 and _rel(z.grad, zr.grad) < 1e-5 and _rel(q.grad, qr.grad) < 1e-5
+    a, b = torch.randn(1000, 7, generator=g), torch.randn(1000, 7, generator=g)
+    assert _rel(Fn.add(a.cuda().to(dtype), b.cuda().to(dtype)).float(), a.to(dtype).float() + b.to(dtype).float()) < tol
+    c = Fn.cast(a.cuda(), torch.bfloat16)
+    assert torch.equal(c.cpu(), a.bfloat16())  # round-to-nearest-even like torch
+
+
+def test_nan_to_num_and_dropout():
+    from deepcoro_clip_amd import kernels as K
+
+    x = torch.tensor([1.0, float("nan"), float("inf"), -float("inf"), -2.0] * 1001, device="cuda")
+    K.nan_to_num_(x, 0.0, 1e4, -1e4)
+    assert torch.equal(x.cpu(), torch.tensor([1.0, 0.0, 1e4, -1e4, -2.0] * 1001))
+    y = torch.ones(1 << 20, device="cuda")
+    m = K.dropout(y, 0.25, seed=123)
+    kept = (m != 0).float().mean().item()
+    assert abs(kept - 0.75) < 5e-3
+    assert torch.allclose(m[m != 0], torch.tensor(1 / 0.75, device="cuda"))
+    assert torch.equal(m, K.dropout(y, 0.25, seed=123)) and not torch.equal(m, K.dropout(y, 0.25, seed=124))

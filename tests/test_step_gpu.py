@@ -1,0 +1,180 @@
+"""Step tail and whole-step parity: HIP AdamW / gradient clipping against torch.optim / clip_grad_norm_, and
+`_train_step` loss curves against the CPU oracle trained with torch.optim.AdamW on the same seeded batches
+(reference ordering: runners/video_constrative_learning_runner.py:1387-1424)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1,), (7,), (96, 3, 3, 7, 7), (4096,), (4097,), (768, 768), (30522, 8), (3, 5, 1)]
+
+
+def _params(seed, device):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter(torch.randn(s, generator=g).to(device)) for s in SHAPES]
+
+
+def _set_grads(ps, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    for p in ps:
+        p.grad = (torch.randn(p.shape, generator=g) * scale).to(p.device)
+
+
+@pytest.mark.parametrize("adamw", [True, False])
+def test_adam_matches_torch(adamw):
+    from deepcoro_clip_amd.optim import HipAdamW
+
+    ref_p, hip_p = _params(0, "cpu"), _params(0, "cuda")
+    mk = lambda ps: [{"params": ps[:3], "lr": 1e-2, "weight_decay": 0.05}, {"params": ps[3:], "lr": 3e-3, "weight_decay": 0.0}]  # noqa: E731
+    ref = (torch.optim.AdamW if adamw else torch.optim.Adam)(mk(ref_p), lr=1e-3, betas=(0.9, 0.98), eps=1e-6)
+    hip = HipAdamW(mk(hip_p), lr=1e-3, betas=(0.9, 0.98), eps=1e-6, adamw=adamw)
+    for step in range(6):
+        _set_grads(ref_p, 10 + step)
+        _set_grads(hip_p, 10 + step)
+        if step == 3:  # a parameter without gradient is skipped, like torch
+            ref_p[1].grad = None
+            hip_p[1].grad = None
+        ref.step()
+        hip.step()
+    for a, b in zip(hip_p, ref_p):
+        assert torch.allclose(a.detach().cpu(), b.detach(), rtol=2e-5, atol=2e-6), (a.shape, (a.cpu() - b).abs().max())
+    st_h, st_r = hip.state[hip_p[5]], ref.state[ref_p[5]]
+    assert float(st_h["step"]) == float(st_r["step"]) == 6
+    assert torch.allclose(st_h["exp_avg"].cpu(), st_r["exp_avg"], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(st_h["exp_avg_sq"].cpu(), st_r["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+
+
+def test_adopt_keeps_groups_and_state():
+    from deepcoro_clip_amd.optim import HipAdamW
+
+    ref_p, hip_p = _params(1, "cpu"), _params(1, "cuda")
+    ref = torch.optim.AdamW(ref_p, lr=1e-2)
+    base = torch.optim.AdamW(hip_p, lr=1e-2)
+    _set_grads(ref_p, 5)
+    _set_grads(hip_p, 5)
+    ref.step()
+    base.step()  # torch's own CUDA step creates the state ...
+    hip = HipAdamW.adopt(base)  # ... which the HIP optimizer continues from
+    assert all(a is b for a, b in zip(hip.param_groups, base.param_groups)) and hip.state is base.state
+    _set_grads(ref_p, 6)
+    _set_grads(hip_p, 6)
+    ref.step()
+    hip.step()
+    for a, b in zip(hip_p, ref_p):
+        assert torch.allclose(a.detach().cpu(), b.detach(), rtol=2e-5, atol=2e-6)
+    with pytest.raises(Exception):
+        HipAdamW.adopt(torch.optim.SGD(hip_p, lr=0.1))
+
+
+@pytest.mark.parametrize("scale,max_norm", [(1.0, 5.0), (1e-4, 5.0), (30.0, 1.0)])
+def test_grad_clip_matches_torch(scale, max_norm):
+    from deepcoro_clip_amd.optim import GradClipper
+
+    ref_p, hip_p = _params(2, "cpu"), _params(2, "cuda")
+    _set_grads(ref_p, 3, scale)
+    _set_grads(hip_p, 3, scale)
+    hip_p[2].grad = None
+    ref_p[2].grad = None
+    total = torch.nn.utils.clip_grad_norm_(ref_p, max_norm)
+    norm = GradClipper(hip_p).clip_(max_norm)
+    assert norm.is_cuda and abs(norm.item() - total.item()) < 1e-5 * max(1.0, total.item())
+    for a, b in zip(hip_p, ref_p):
+        if b.grad is not None:
+            assert torch.allclose(a.grad.cpu(), b.grad, rtol=1e-5, atol=1e-9)
+
+
+def _oracle_trainer(vo, to, log_temp0):
+    lt = torch.nn.Parameter(torch.log(torch.tensor([log_temp0])))
+    groups = [{"params": list(vo.model.parameters()), "lr": 1e-4, "weight_decay": 0.01},
+              {"params": list(vo.aggregator.parameters()), "lr": 2e-4, "weight_decay": 0.01},
+              {"params": list(to.parameters()), "lr": 2e-5, "weight_decay": 0.01},
+              {"params": [lt], "lr": 1e-4}]
+    return lt, torch.optim.AdamW(groups, lr=1e-4)
+
+
+@pytest.mark.parametrize("dtype,steps,tol", [(torch.float32, 8, 1e-4), (torch.bfloat16, 20, 1e-2)])
+def test_train_step_loss_curve_vs_oracle(dtype, steps, tol):
+    """Same weights, same batches, same optimizer on both sides: loss per step within north_star's tolerance
+    (1e-4 fp32 / 1e-2 bf16), metric keys of the reference, embeddings' argmax identical at step 0."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import make_tiny_setup
+    from oracle.losses import contrastive_loss, step_metrics
+
+    B = 4
+    runner, (vo, to), _ = make_tiny_setup(dtype, B=B)
+    lt, opt = _oracle_trainer(vo, to, 0.07)
+    all_params = list(vo.parameters()) + list(to.parameters())
+    g = torch.Generator().manual_seed(99)
+    worst = 0.0
+    for step in range(steps):
+        videos = torch.randn(B, 4, 64, 64, 3, generator=g)
+        ids = torch.randint(0, 512, (B, 16), generator=g)
+        mask = torch.ones(B, 16, dtype=torch.int64)
+        mask[1, 11:] = 0  # one padded sequence
+        opt.zero_grad(set_to_none=True)
+        v, t = vo(videos), to(ids, mask)
+        ref = contrastive_loss(v, t, lt)
+        ref_m = step_metrics(v.detach(), t.detach(), lt.detach())
+        ref.backward()
+        torch.nn.utils.clip_grad_norm_(all_params, 5.0)
+        opt.step()
+        m, emb = runner._train_step(videos=videos.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda())
+        err = abs(m["loss"] - ref.item()) / max(1.0, abs(ref.item()))
+        worst = max(worst, err)
+        assert err < tol, (step, m["loss"], ref.item())
+        if step == 0:
+            for key in ("loss", "temperature", "contrastive/clip_loss", "video_norm", "text_norm", "alignment_score",
+                        "alignment_logprob", "alignment_cosine", "lr/video_backbone", "lr/text_encoder", "lr/temperature"):
+                assert key in m, key
+            assert abs(m["temperature"] - math.exp(lt.item())) < 1e-6  # reported after the update, like the reference
+            mt = 1e-3 if dtype == torch.float32 else 3e-2
+            assert abs(m["video_norm"] - ref_m["video_norm"]) < mt * max(1, ref_m["video_norm"])
+            assert abs(m["text_norm"] - ref_m["text_norm"]) < mt * max(1, ref_m["text_norm"])
+            assert abs(m["alignment_cosine"] - ref_m["alignment_cosine"]) < mt
+            assert abs(m["alignment_score"] - ref_m["alignment_score"]) < mt
+            assert emb["video_embeddings"].shape == (B, 512) and emb["video_embeddings"].dtype == torch.float32
+            sim = torch.nn.functional.normalize(emb["video_embeddings"], dim=1) @ torch.nn.functional.normalize(emb["text_embeddings"], dim=1).t()
+            sim_ref = torch.nn.functional.normalize(v.detach(), dim=1) @ torch.nn.functional.normalize(t.detach(), dim=1).t()
+            if dtype == torch.float32:
+                assert torch.equal(sim.argmax(1).cpu(), sim_ref.argmax(1))
+    # parameters stay together too (fp32): temperature after `steps` updates
+    if dtype == torch.float32:
+        assert abs(runner.log_temp.item() - lt.item()) < 1e-5
+    print(f"[loss-curve] {dtype} worst relative deviation over {steps} steps: {worst:.2e}")
+
+
+def test_gradient_accumulation_and_val_step():
+    """accum=2: the optimizer moves only on the boundary step and sees the mean gradient (runner.py:1223-1224,
+    1387-1424 of the reference); _val_step leaves parameters and grads alone and drops the lr/ keys."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import make_tiny_setup
+    from oracle.losses import contrastive_loss
+
+    runner, (vo, to), (videos, ids, mask) = make_tiny_setup(torch.float32, B=2)
+    runner.config.gradient_accumulation_steps = 2
+    lt, opt = _oracle_trainer(vo, to, 0.07)
+    g = torch.Generator().manual_seed(5)
+    batches = [(torch.randn(2, 4, 64, 64, 3, generator=g), torch.randint(0, 512, (2, 16), generator=g)) for _ in range(2)]
+    p0 = runner.video_encoder.model.blocks[0].attn.qkv.weight.detach().clone()
+    opt.zero_grad()
+    for i, (vid, tok) in enumerate(batches):
+        (contrastive_loss(vo(vid), to(tok, mask), lt) / 2).backward()
+        m, _ = runner._train_step(videos=vid.cuda(), input_ids=tok.cuda(), attention_mask=mask.cuda())
+        changed = not torch.equal(runner.video_encoder.model.blocks[0].attn.qkv.weight.detach(), p0)
+        assert changed == (i == 1)
+    torch.nn.utils.clip_grad_norm_(list(vo.parameters()) + list(to.parameters()), 5.0)
+    opt.step()
+    w_ref = vo.model.blocks[0].attn.qkv.weight.detach()
+    w_hip = runner.video_encoder.model.blocks[0].attn.qkv.weight.detach().cpu()
+    assert torch.allclose(w_hip, w_ref, atol=2e-6), (w_hip - w_ref).abs().max()
+    before = w_hip.clone()
+    vm, emb = runner._val_step(videos=videos.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda())
+    assert not any(k.startswith("lr/") for k in vm) and math.isfinite(vm["loss"])
+    with torch.no_grad():
+        ref = contrastive_loss(vo(videos), to(ids, mask), lt).item()
+    assert abs(vm["loss"] - ref) < 1e-4 * max(1.0, abs(ref))
+    assert torch.equal(runner.video_encoder.model.blocks[0].attn.qkv.weight.detach().cpu(), before)
