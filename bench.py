@@ -81,16 +81,37 @@ def build_job(args, device, world, rank):
     return runner, dict(videos=videos, input_ids=ids, attention_mask=mask)
 
 
-def cpu_baseline(args):
-    """The CPU oracle (a port of the reference algorithm) timed on this host: fwd + bwd + AdamW, bounded sample."""
-    from oracle.losses import contrastive_loss
-    from oracle.model import TextEncoderOracle, VideoEncoderOracle, init_by_name
-
+def _host_cores() -> int:
+    """CPU share of this process: affinity mask, capped by the cgroup quota; a GPU box gives 16 cores per GPU, and
+    oversubscribing torch's thread pool beyond the quota makes the baseline collapse rather than speed up."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    cores = min(cores, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, min(cores, 16))
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a port of the reference algorithm) timed on this host: fwd + bwd + AdamW, bounded sample."""
+    from oracle.losses import contrastive_loss
+    from oracle.model import TextEncoderOracle, VideoEncoderOracle, init_by_name
+
+    cores = _host_cores()
     torch.set_num_threads(cores)
     B = 2
     vo = init_by_name(VideoEncoderOracle(args.frames, (args.size, args.size)))
@@ -109,12 +130,15 @@ def cpu_baseline(args):
         torch.nn.utils.clip_grad_norm_(list(vo.parameters()) + list(to.parameters()), 5.0)
         opt.step()
 
+    tw = time.perf_counter()
     step()  # warm-up (allocator, thread pool)
+    print(f"[bench] cpu_baseline: warm-up step {time.perf_counter() - tw:.1f} s on {cores} threads", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     n = 0
-    while n < 2 or (time.perf_counter() - t0 < 12.0 and n < 8):
+    while n < 1 or (time.perf_counter() - t0 < 15.0 and n < 8):
         step()
         n += 1
+        print(f"[bench] cpu_baseline: {n} timed steps, {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
     return {"value": B * n / dt, "unit": "clip-pairs/s", "cores": cores, "kind": "port",
             "sample": f"{n} fp32 training steps of B={B} clips {args.frames}x{args.size}x{args.size} + {args.seq}-token texts, "
@@ -221,7 +245,8 @@ def main():
                        f"multi-video CLIP step: MViT-v2-S {args.frames}x{args.size}x{args.size} x N={args.videos} + "
                        f"{args.pooling} pooling + aggregator, BERT-base S={args.seq}, B={args.batch}/GPU",
                        "global_batch": pairs_per_step, "clips_per_step": clips_per_step, "seq_len": args.seq,
-                       "parallelism": f"dp{world}", "loss_first": loss0, "loss_last": m["loss"]},
+                       "parallelism": f"dp{world}", "loss_first": loss0, "loss_last": m["loss"],
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

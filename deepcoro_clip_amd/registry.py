@@ -54,6 +54,22 @@ class LossRegistry(BaseRegistry):
     _registry_type = "loss"
 
 
+def _adopt_reference_registries() -> None:
+    """Inside the reference tree (its `utils.registry` importable), register into the reference's OWN singletons so
+    that `projects/contrastive_pretraining_project.py` resolves the HIP classes without any other change."""
+    global RunnerRegistry, ModelRegistry, LossRegistry
+    try:
+        ref = importlib.import_module("utils.registry")
+        trio = (ref.RunnerRegistry, ref.ModelRegistry, ref.LossRegistry)
+        if all(hasattr(r, "register") and hasattr(r, "get") and isinstance(getattr(r, "_registry", None), dict) for r in trio):
+            RunnerRegistry, ModelRegistry, LossRegistry = trio
+    except Exception:  # not inside the reference tree: keep the identical local registries
+        pass
+
+
+_adopt_reference_registries()
+
+
 def register_submodules(package_name: str = "deepcoro_clip_amd", recursive: bool = True) -> None:
     """Import every submodule so that the @register decorators run (utils/registry.py:82-94)."""
     package = importlib.import_module(package_name)
