@@ -14,29 +14,7 @@
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles.
 #include "common.h"
 
-#define GEMM_BIAS 1
-#define GEMM_GELU 2
-#define GEMM_SAVE_PRE 4
-#define GEMM_RESID 8
-#define GEMM_DGELU 16
-#define GEMM_ACCUM 32
-#define GEMM_COLSUM_A 64
-
-struct GemmParams {
-  const void* A;
-  const void* B;
-  void* C;
-  const float* bias;
-  const void* R;
-  void* aux;
-  float* colsum;  // GEMM_COLSUM_A: colsum[m] += sum_k A(m,k)   (bias gradient fused into the weight-gradient GEMM)
-  int64_t lda, ldb, ldc, ldr, ldaux;
-  int64_t sA, sB, sC;
-  int M, N, K;
-  int batch, splitk;
-  float alpha;
-  int flags;
-};
+#include "gemm_params.h"
 
 namespace {
 
@@ -471,12 +449,16 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   hipStream_t st = (hipStream_t)stream;
   // tile choice: 128x128 unless that leaves most of the 256 CUs idle
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch * splitk;
-  const bool small = in_dtype == DCC_BF16 && t128 < 192;
+  const int variant = (flags >> 8) & 0xff;  // tuning knob (bench / tests only): 1 = BK 32 for the 128-tile bf16 kernels, 2 = 64x64 tiles, 3 = no ring kernel
+  const bool small = in_dtype == DCC_BF16 && (t128 < 192 || variant == 2);
   const int bmn = small ? 64 : 128;
+  if (in_dtype == DCC_BF16 && aligned && !small && variant != 3) {  // the towers' large GEMMs: persistent LDS-DMA ring kernel
+    const int rc = dcc_gemm_ring_launch(p, a_km, b_km, out_dtype, st);
+    if (rc != DCC_ERR_UNSUPPORTED) return rc;
+  }
   const int64_t tiles = (int64_t)((M + bmn - 1) / bmn) * ((N + bmn - 1) / bmn);
   if (tiles > 0x7fffffffLL) return DCC_ERR_ARG;
   dim3 grid((unsigned)tiles, 1, (unsigned)(batch * splitk));
-  const int variant = (flags >> 8) & 0xff;  // tuning knob (bench / tests only): 1 = BK 32 for the 128-tile bf16 kernels
   if (in_dtype == DCC_BF16 && out_dtype == DCC_BF16) {
     if (small) return launch_layout<bf16_t, bf16_t, 1, 64, true>(p, a_km, b_km, grid, st);
     return variant == 1 ? launch_layout<bf16_t, bf16_t, 2, 32, true>(p, a_km, b_km, grid, st)

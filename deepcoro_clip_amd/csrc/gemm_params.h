@@ -1,0 +1,32 @@
+// Parameter block and epilogue flags shared by the two GEMM kernels (gemm.hip: register-staged tiles for fp32 /
+// small / odd shapes; gemm_ring.hip: persistent LDS-DMA ring kernel for the large bf16 GEMMs of the towers).
+#pragma once
+#include "common.h"
+
+#define GEMM_BIAS 1
+#define GEMM_GELU 2
+#define GEMM_SAVE_PRE 4
+#define GEMM_RESID 8
+#define GEMM_DGELU 16
+#define GEMM_ACCUM 32
+#define GEMM_COLSUM_A 64
+
+struct GemmParams {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;
+  const void* R;
+  void* aux;
+  float* colsum;  // GEMM_COLSUM_A: colsum[m] += sum_k A(m,k)   (bias gradient fused into the weight-gradient GEMM)
+  int64_t lda, ldb, ldc, ldr, ldaux;
+  int64_t sA, sB, sC;
+  int M, N, K;
+  int batch, splitk;
+  float alpha;
+  int flags;
+};
+
+// Persistent ring kernel (gemm_ring.hip). Returns DCC_OK, or DCC_ERR_UNSUPPORTED when the shape/layout is outside
+// what it handles (the caller then runs the register-staged kernel).
+int dcc_gemm_ring_launch(const GemmParams& p, int a_km, int b_km, int out_dtype, hipStream_t stream);

@@ -157,15 +157,23 @@ def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=N
     return out
 
 
+_NICE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 128)
+
+
 def wgrad_splitk(rows: int, n: int, k: int) -> int:
     """Split factor for weight-gradient GEMMs (reduction over `rows`, output n x k).
 
-    Measured on MI355X (scratch/wgrad_sweep.py): the fp32 atomics of the split-K epilogue are served at the memory
-    side, so the fastest split is the SMALLEST one that still gives every CU a block (~160 blocks of 128x128 output
-    tiles); only outputs of a few tiles want more (their blocks are otherwise too few and too long)."""
+    Measured on MI355X (scratch/wgrad_sweep.py) with the persistent ring kernel: one work item (128x128 output tile x
+    K split) per CU is the sweet spot — fewer leave CUs idle, more only add fp32 atomics (served at the memory side).
+    So: the largest "nice" split with tiles x split <= 256 CUs; outputs with more than 128 tiles still take a split of 2
+    when the reduction is long, which evens out the second round of items."""
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
-    want = round(160 / tiles) if tiles >= 4 else 384 // tiles
-    return int(max(1, min(want, rows // 128, 512)))
+    ksteps = (rows + 63) // 64
+    if tiles > 128:
+        want = 2 if ksteps >= 64 else 1
+    else:
+        want = max(s for s in _NICE_SPLITS if s * tiles <= 256)
+    return int(max(1, min(want, ksteps // 4)))
 
 
 # ------------------------------------------------------------------------------------ attention

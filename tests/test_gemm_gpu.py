@@ -102,3 +102,102 @@ def test_gemm_splitk_accumulate():
     out = Kx.gemm(dy, x, a_km=True, b_km=True, out_dtype=torch.float32, splitk=8)
     ref = dy.float().t().double() @ x.float().double()
     assert (out.double() - ref).abs().max() < 1e-3 * ref.abs().max()
+
+
+# ------------------------------------------------------------------ persistent LDS-DMA ring kernel (csrc/gemm_ring.hip)
+# bf16 shapes with >= 192 tile-splits take the ring kernel; every case is checked with exact small-integer data
+# first (any mis-placed chunk of the swizzled LDS images, any stale ring stage or mis-counted wait shows up as a wrong
+# integer) and then with random data against fp64.
+def _ring_case(M, N, K, a_km, b_km, out_dtype=torch.float32, splitk=1, seed=0, **kw):
+    from deepcoro_clip_amd import kernels as Kx
+
+    g = torch.Generator(device="cpu").manual_seed(seed + M + 3 * N + 7 * K)
+    ai = torch.randint(-2, 3, (K, M) if a_km else (M, K), generator=g).to("cuda", torch.bfloat16)
+    bi = torch.randint(-2, 3, (K, N) if b_km else (N, K), generator=g).to("cuda", torch.bfloat16)
+    out = Kx.gemm(ai, bi, a_km=a_km, b_km=b_km, out_dtype=out_dtype, splitk=splitk, **kw)
+    return out, _ref(ai, bi, a_km, b_km)
+
+
+@pytest.mark.parametrize("a_km,b_km", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(3000, 1536, 384), (2049, 1160, 192), (25089, 96, 128), (1569, 3072, 64), (4096, 512, 1024)])
+def test_ring_layouts_exact(a_km, b_km, M, N, K):
+    if (a_km and M % 8) or (b_km and N % 8):
+        pytest.skip("k-major operands need 16-byte row chunks")
+    out, ref = _ring_case(M, N, K, a_km, b_km)
+    assert torch.equal(out.double(), ref)
+    out16, _ = _ring_case(M, N, K, a_km, b_km, out_dtype=torch.bfloat16)
+    assert torch.equal(out16.double(), ref.to(torch.bfloat16).double())
+
+
+@pytest.mark.parametrize("splitk", [2, 7, 64])
+@pytest.mark.parametrize("Kred,M,N", [(37656, 384, 1536), (9432, 768, 768), (150552, 96, 288), (5000, 1152, 384)])
+def test_ring_splitk_wgrad_exact(splitk, Kred, M, N):
+    """Weight-gradient shapes: both operands k-major, ragged K tail zero-filled by the buffer range check, fp32
+    atomics, fused bias gradient (row sums of dY on the matrix core)."""
+    from deepcoro_clip_amd import kernels as Kx
+
+    g = torch.Generator(device="cpu").manual_seed(splitk + Kred)
+    dy = torch.randint(-2, 3, (Kred, M), generator=g).to("cuda", torch.bfloat16)
+    x = torch.randint(-2, 3, (Kred, N), generator=g).to("cuda", torch.bfloat16)
+    db = torch.zeros(M, device="cuda")
+    dw = torch.zeros(M, N, device="cuda")
+    Kx.gemm(dy, x, a_km=True, b_km=True, out=dw, accumulate=True, splitk=splitk, colsum=db)
+    assert torch.equal(dw.double(), dy.double().t() @ x.double())
+    assert torch.equal(db.double(), dy.double().sum(0))
+    Kx.gemm(dy, x, a_km=True, b_km=True, out=dw, accumulate=True, splitk=splitk, colsum=db)  # accumulates
+    assert torch.equal(dw.double(), 2 * (dy.double().t() @ x.double()))
+
+
+def test_ring_epilogues_and_random_data():
+    from deepcoro_clip_amd import kernels as Kx
+
+    g = torch.Generator(device="cpu").manual_seed(21)
+    M, N, K = 5001, 1536, 384
+    a = torch.randn(M, K, generator=g).to("cuda", torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to("cuda", torch.bfloat16)
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to("cuda", torch.bfloat16)
+    pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    out = Kx.gemm(a, w, bias=bias, gelu=True, save_pre=True, aux=pre, resid=res)
+    ref_pre = a.double() @ w.double().t() + bias.double()
+    ref = torch.nn.functional.gelu(ref_pre) + res.double()
+    assert (pre.double() - ref_pre).abs().max() < 2e-2 * ref_pre.abs().max()
+    assert (out.double() - ref).abs().max() < 2e-2 * ref.abs().max()
+    out2 = Kx.gemm(a, w, dgelu=True, aux=pre, alpha=0.5)
+    x = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    ref2 = 0.5 * (a.double() @ w.double().t()) * x.grad
+    assert (out2.double() - ref2).abs().max() < 2e-2 * ref2.abs().max()
+    # strided output / residual views (a column slice of a wider buffer), bias only
+    wide = torch.zeros(M, 2 * N, device="cuda", dtype=torch.bfloat16)
+    Kx.gemm(a, w, bias=bias, out=wide[:, N:])
+    assert (wide[:, N:].double() - ref_pre).abs().max() < 2e-2 * ref_pre.abs().max()
+    assert wide[:, :N].abs().max() == 0
+
+
+def test_ring_batched_and_matches_staged_kernel():
+    """Batched form (patch embedding) and bit-identical results between the two GEMM kernels on the same inputs
+    (same MFMA, same K order within a tile => identical fp32 sums when nothing is split)."""
+    from deepcoro_clip_amd import kernels as Kx
+
+    g = torch.Generator(device="cpu").manual_seed(4)
+    Bn, L, Kp, Co = 24, 1568, 448, 96
+    col = torch.randn(Bn * L, Kp, generator=g).to("cuda", torch.bfloat16)
+    w = (torch.randn(Co, Kp, generator=g) * 0.05).to("cuda", torch.bfloat16)
+    bias = torch.randn(Co, generator=g).cuda()
+    out = torch.zeros(Bn, L + 1, Co, device="cuda", dtype=torch.bfloat16)
+    Kx.gemm_batched(col, w, out[:, 1:], M=L, N=Co, K=Kp, lda=Kp, ldb=Kp, ldc=Co, batch=Bn, sA=L * Kp, sB=0,
+                    sC=(L + 1) * Co, bias=bias)
+    ref = (col.double() @ w.double().t() + bias.double()).view(Bn, L, Co)
+    assert (out[:, 1:].double() - ref).abs().max() < 2e-2 * ref.abs().max()
+    assert out[:, 0].abs().max() == 0
+    a = torch.randn(6000, 768, generator=g).to("cuda", torch.bfloat16)
+    b = torch.randn(1152, 768, generator=g).to("cuda", torch.bfloat16)
+    o_ring = Kx.gemm(a, b, out_dtype=torch.float32)
+    old = Kx.GEMM_VARIANT
+    try:
+        Kx.GEMM_VARIANT = 3 << 8  # force the register-staged kernel
+        o_staged = Kx.gemm(a, b, out_dtype=torch.float32)
+    finally:
+        Kx.GEMM_VARIANT = old
+    assert torch.equal(o_ring, o_staged)
