@@ -317,6 +317,323 @@ __global__ __launch_bounds__(256) void dwconv_reduce_kernel(const float* __restr
   }
 }
 
+// =====================================================================================================
+// Specialised depthwise 3x3x3 kernels (padding 1, temporal stride 1, spatial stride S in {1,2,4,8}: every
+// q/k/v pool of MViT-v2-S).  The generic kernels above spend most of their instructions on 64-bit index
+// arithmetic and re-fetch every input up to 27 times; here
+//   * a thread owns one 16-byte channel chunk of a RUN of WT consecutive output columns of one output row, so an
+//     input row segment is fetched once per (kt, kh) and feeds all 3 kw taps of all WT outputs (11.6 instead of
+//     27 vector loads per output for S = 1, WT = 7; MViT's grids 56/28/14/7 are multiples of 7);
+//   * indices are 32-bit with multiply-shift division by launch constants, taps are compile-time;
+//   * the data gradient of a stride-1 pool is the same stencil with mirrored taps; the data gradient of a
+//     strided pool enumerates exactly the taps that reach an input position (1-2 per axis instead of 3 tests);
+//   * the weight gradient keeps one temporal tap per thread (72 accumulators), folds the threads of a block
+//     through LDS without atomics and writes one partial per block for dwconv_reduce_kernel.
+struct FastDiv { unsigned d; unsigned long long m; };
+inline FastDiv mkdiv(unsigned d) { FastDiv f; f.d = d ? d : 1; f.m = ((1ull << 40) / f.d) + 1; return f; }
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return (unsigned)(((unsigned long long)n * f.m) >> 40); }
+
+struct RunGeom {
+  PoolGeom g;
+  int runsW, runs, cpr, slots;
+  FastDiv d_cpr, d_runsW, d_Ho, d_To, d_H, d_Ws, d_Hs, d_T;
+};
+
+template <typename TD, int CV> __device__ __forceinline__ void load_cv(const TD* p, float* f) {
+  if constexpr (sizeof(TD) == 2) {
+    static_assert(CV == 8, "bf16 chunks are 8 wide");
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+  } else {
+#pragma unroll
+    for (int q = 0; q < CV / 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * q);
+      f[4 * q] = v[0]; f[4 * q + 1] = v[1]; f[4 * q + 2] = v[2]; f[4 * q + 3] = v[3];
+    }
+  }
+}
+template <typename T, int CV> __device__ __forceinline__ void store_cv(T* p, const float* f) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)f[e];
+    *reinterpret_cast<bf16x8*>(p) = o;
+  } else {
+#pragma unroll
+    for (int q = 0; q < CV / 4; ++q) *reinterpret_cast<f32x4*>(p + 4 * q) = f32x4{f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
+  }
+}
+
+// run index -> (b, head, to, ho, first output column)
+struct RunPos { int b, hd, to, ho, w0; };
+__device__ __forceinline__ RunPos run_pos(unsigned run, const RunGeom& r, int WT) {
+  RunPos p;
+  const unsigned t1 = fdiv(run, r.d_runsW);
+  p.w0 = (run - t1 * r.runsW) * WT;
+  const unsigned t2 = fdiv(t1, r.d_Ho);
+  p.ho = t1 - t2 * r.g.Ho;
+  const unsigned t3 = fdiv(t2, r.d_To);
+  p.to = t2 - t3 * r.g.To;
+  const unsigned t4 = fdiv(t3, r.d_H);
+  p.hd = t3 - t4 * r.g.H;
+  p.b = t4;
+  return p;
+}
+
+// forward (x = input, y = output) or stride-1 data gradient (MIRROR: x = dy, y = dx, taps mirrored)
+template <typename T, typename TD, int S, int WT, bool MIRROR>
+__global__ __launch_bounds__(256) void dw3_run_kernel(const TD* __restrict__ x, T* __restrict__ y,
+                                                      const float* __restrict__ w, RunGeom r) {
+  constexpr int CV = Vec16<T>::N;
+  constexpr int SEG = (WT - 1) * S + 3;
+  extern __shared__ __attribute__((aligned(16))) float wl3[];  // [27][C]
+  const PoolGeom& g = r.g;
+  for (int i = threadIdx.x; i < 27 * g.C; i += 256) {
+    const int k = i / g.C, c = i - k * g.C;
+    wl3[i] = w[c * 27 + (MIRROR ? 26 - k : k)];
+  }
+  __syncthreads();
+  const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
+  const int c = threadIdx.x - rs * r.cpr;
+  if ((int)rs >= r.slots) return;
+  const unsigned run = blockIdx.x * r.slots + rs;
+  if ((int)run >= r.runs) {  // class tokens bypass the pooling
+    const int i = run - r.runs;
+    if (g.has_cls && i < g.B * g.H) {
+      const int b = i / g.H, hd = i - b * g.H;
+      float f[CV];
+      load_cv<TD, CV>(x + b * g.sxb + hd * g.sxh + c * CV, f);
+      store_cv<T, CV>(y + b * g.syb + hd * g.syh + c * CV, f);
+    }
+    return;
+  }
+  const RunPos p = run_pos(run, r, WT);
+  const TD* xb = x + p.b * g.sxb + p.hd * g.sxh + c * CV;
+  T* yb = y + p.b * g.syb + p.hd * g.syh + c * CV;
+  float acc[WT][CV];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int e = 0; e < CV; ++e) acc[i][e] = 0.0f;
+  const int col0 = p.w0 * S - 1;
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+    const int t = p.to + kt - 1;
+    if (t < 0 || t >= g.T) continue;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = p.ho * S + kh - 1;
+      if (hh < 0 || hh >= g.Hs) continue;
+      const TD* row = xb + (int64_t)(g.has_cls + (t * g.Hs + hh) * g.Ws) * g.sxn;
+      float wt[3][CV];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float* wp = wl3 + ((kt * 3 + kh) * 3 + kw) * g.C + c * CV;
+#pragma unroll
+        for (int q = 0; q < CV / 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+          wt[kw][4 * q] = v[0]; wt[kw][4 * q + 1] = v[1]; wt[kw][4 * q + 2] = v[2]; wt[kw][4 * q + 3] = v[3];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < SEG; ++j) {
+        if (S > 2 && (j % S) > 2) continue;  // columns between the windows of a wide stride are never used
+        const int col = col0 + j;
+        float f[CV];
+#pragma unroll
+        for (int e = 0; e < CV; ++e) f[e] = 0.0f;
+        if (col >= 0 && col < g.Ws) load_cv<TD, CV>(row + (int64_t)col * g.sxn, f);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          if ((j - kw) >= 0 && (j - kw) % S == 0 && (j - kw) / S < WT) {
+#pragma unroll
+            for (int e = 0; e < CV; ++e) acc[(j - kw) / S][e] += f[e] * wt[kw][e];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < WT; ++i) {
+    const int wo = p.w0 + i;
+    if (wo < g.Wo) store_cv<T, CV>(yb + (int64_t)(g.has_cls + (p.to * g.Ho + p.ho) * g.Wo + wo) * g.syn, acc[i]);
+  }
+}
+
+// data gradient of a strided pool (S >= 2): one thread per input position chunk, exact tap enumeration.
+// x-strides describe dx, y-strides dy (as dcc_pool_bwd_data).
+template <typename T, typename TD, int S>
+__global__ __launch_bounds__(256) void dw3_bwd_data_strided_kernel(const TD* __restrict__ dy, T* __restrict__ dx,
+                                                                   const float* __restrict__ w, RunGeom r) {
+  constexpr int CV = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float wl3[];
+  const PoolGeom& g = r.g;
+  for (int i = threadIdx.x; i < 27 * g.C; i += 256) {
+    const int k = i / g.C, c = i - k * g.C;
+    wl3[i] = w[c * 27 + k];
+  }
+  __syncthreads();
+  const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
+  const int c = threadIdx.x - rs * r.cpr;
+  if ((int)rs >= r.slots) return;
+  const unsigned id = blockIdx.x * r.slots + rs;  // position index over (b, head, t, h, w), then class tokens
+  const int npos = g.B * g.H * g.T * g.Hs * g.Ws;
+  float acc[CV];
+#pragma unroll
+  for (int e = 0; e < CV; ++e) acc[e] = 0.0f;
+  if ((int)id >= npos) {
+    const int i = id - npos;
+    if (g.has_cls && i < g.B * g.H) {
+      const int b = i / g.H, hd = i - b * g.H;
+      load_cv<TD, CV>(dy + b * g.syb + hd * g.syh + c * CV, acc);
+      store_cv<T, CV>(dx + b * g.sxb + hd * g.sxh + c * CV, acc);
+    }
+    return;
+  }
+  const unsigned t1 = fdiv(id, r.d_Ws);
+  const int ww = id - t1 * g.Ws;
+  const unsigned t2 = fdiv(t1, r.d_Hs);
+  const int hh = t1 - t2 * g.Hs;
+  const unsigned t3 = fdiv(t2, r.d_T);
+  const int t = t2 - t3 * g.T;
+  const unsigned t4 = fdiv(t3, r.d_H);
+  const int hd = t3 - t4 * g.H, b = t4;
+  // taps (k, o) with o * S - 1 + k == coordinate
+  int khs[2], hos[2], nh = 0, kws[2], wos[2], nw = 0;
+  auto taps = [](int x, int lim, int* ks, int* os) {
+    int n = 0;
+    if (S == 2) {
+      if ((x & 1) == 0) { ks[0] = 1; os[0] = x >> 1; n = 1; }
+      else { ks[0] = 0; os[0] = (x + 1) >> 1; ks[1] = 2; os[1] = (x - 1) >> 1; n = 2; }
+    } else {
+      const int rem = (x + 1) & (S - 1);
+      if (rem <= 2) { ks[0] = rem; os[0] = (x + 1 - rem) / S; n = 1; }
+    }
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+      if (os[i] < lim) { ks[m] = ks[i]; os[m] = os[i]; ++m; }
+    return m;
+  };
+  nh = taps(hh, g.Ho, khs, hos);
+  nw = taps(ww, g.Wo, kws, wos);
+  const TD* dyb = dy + b * g.syb + hd * g.syh + c * CV;
+  if (nh && nw) {
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const int to = t + 1 - kt;
+      if (to < 0 || to >= g.To) continue;
+      for (int a = 0; a < nh; ++a)
+        for (int bb = 0; bb < nw; ++bb) {
+          float f[CV];
+          load_cv<TD, CV>(dyb + (int64_t)(g.has_cls + (to * g.Ho + hos[a]) * g.Wo + wos[bb]) * g.syn, f);
+          const float* wp = wl3 + ((kt * 3 + khs[a]) * 3 + kws[bb]) * g.C + c * CV;
+#pragma unroll
+          for (int e = 0; e < CV; ++e) acc[e] += f[e] * wp[e];
+        }
+    }
+  }
+  store_cv<T, CV>(dx + b * g.sxb + (int64_t)(g.has_cls + (t * g.Hs + hh) * g.Ws + ww) * g.sxn + hd * g.sxh + c * CV, acc);
+}
+
+// weight gradient: thread = (chunk, temporal tap kt, run slot); block partial -> ws[blockIdx.x][27][C]
+template <typename T, typename TD, int S, int WT>
+__global__ __launch_bounds__(256) void dw3_wgrad_kernel(const TD* __restrict__ dy, const T* __restrict__ x,
+                                                        float* __restrict__ ws, RunGeom r, int iters) {
+  constexpr int CV = Vec16<T>::N;
+  constexpr int SEG = (WT - 1) * S + 3;
+  constexpr int PITCH = 9 * CV + 1;
+  extern __shared__ __attribute__((aligned(16))) float red3[];  // [256][PITCH]
+  const PoolGeom& g = r.g;
+  const unsigned slot = fdiv(threadIdx.x, r.d_cpr);
+  const int c = threadIdx.x - slot * r.cpr;
+  const int slots3 = r.slots / 3;            // run slots per block
+  const int kt = slot % 3, rsl = slot / 3;
+  float acc[9][CV];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int e = 0; e < CV; ++e) acc[k][e] = 0.0f;
+  if ((int)slot < slots3 * 3) {
+    for (int it = 0; it < iters; ++it) {
+      const unsigned run = (blockIdx.x * iters + it) * slots3 + rsl;
+      if ((int)run >= r.runs) break;
+      const RunPos p = run_pos(run, r, WT);
+      const int t = p.to + kt - 1;
+      if (t < 0 || t >= g.T) continue;
+      float dv[WT][CV];
+      const TD* dyb = dy + p.b * g.syb + p.hd * g.syh + c * CV + (int64_t)(g.has_cls + (p.to * g.Ho + p.ho) * g.Wo) * g.syn;
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+#pragma unroll
+        for (int e = 0; e < CV; ++e) dv[i][e] = 0.0f;
+        if (p.w0 + i < g.Wo) load_cv<TD, CV>(dyb + (int64_t)(p.w0 + i) * g.syn, dv[i]);
+      }
+      const T* xb = x + p.b * g.sxb + p.hd * g.sxh + c * CV;
+      const int col0 = p.w0 * S - 1;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hh = p.ho * S + kh - 1;
+        if (hh < 0 || hh >= g.Hs) continue;
+        const T* row = xb + (int64_t)(g.has_cls + (t * g.Hs + hh) * g.Ws) * g.sxn;
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) {
+          if (S > 2 && (j % S) > 2) continue;
+          const int col = col0 + j;
+          float f[CV];
+#pragma unroll
+          for (int e = 0; e < CV; ++e) f[e] = 0.0f;
+          if (col >= 0 && col < g.Ws) load_cv<T, CV>(row + (int64_t)col * g.sxn, f);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            if ((j - kw) >= 0 && (j - kw) % S == 0 && (j - kw) / S < WT) {
+#pragma unroll
+              for (int e = 0; e < CV; ++e) acc[kh * 3 + kw][e] += dv[(j - kw) / S][e] * f[e];
+            }
+          }
+        }
+      }
+    }
+  }
+  float* mine = red3 + threadIdx.x * PITCH;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int e = 0; e < CV; ++e) mine[k * CV + e] = acc[k][e];
+  __syncthreads();
+  float* part = ws + (int64_t)blockIdx.x * 27 * g.C;
+  for (int o = threadIdx.x; o < 27 * g.C; o += 256) {
+    const int tap = o / g.C, ch = o - tap * g.C;
+    const int okt = tap / 9, k9 = tap - okt * 9;
+    const int oc = ch / CV, oe = ch - oc * CV;
+    float sum = 0.0f;
+    for (int s3 = 0; s3 < slots3; ++s3) sum += red3[((s3 * 3 + okt) * r.cpr + oc) * PITCH + k9 * CV + oe];
+    part[o] = sum;
+  }
+}
+
+RunGeom make_run_geom(const PoolGeom& g, int vec, int WT) {
+  RunGeom r;
+  r.g = g;
+  r.cpr = g.C / vec;
+  r.slots = 256 / r.cpr;
+  r.runsW = (g.Wo + WT - 1) / WT;
+  r.runs = g.B * g.H * g.To * g.Ho * r.runsW;
+  r.d_cpr = mkdiv(r.cpr); r.d_runsW = mkdiv(r.runsW); r.d_Ho = mkdiv(g.Ho); r.d_To = mkdiv(g.To); r.d_H = mkdiv(g.H);
+  r.d_Ws = mkdiv(g.Ws); r.d_Hs = mkdiv(g.Hs); r.d_T = mkdiv(g.T);
+  return r;
+}
+
+// kernel 3x3x3, padding 1, temporal stride 1, equal spatial strides in {1,2,4,8}, index ranges the multiply-shift
+// division covers
+int dw3_stride(const PoolGeom& g, int vec) {
+  if (g.kt != 3 || g.kh != 3 || g.kw != 3 || g.pt != 1 || g.ph != 1 || g.pw != 1 || g.st != 1 || g.sh != g.sw) return 0;
+  if (g.sh != 1 && g.sh != 2 && g.sh != 4 && g.sh != 8) return 0;
+  if (g.C % vec || g.C / vec > 64) return 0;
+  if ((int64_t)g.B * g.H * g.T * g.Hs * g.Ws >= (1 << 25)) return 0;
+  return g.sh;
+}
+
 inline unsigned blocks_for(int64_t total, int per_block, int cap) {
   int64_t b = (total + per_block - 1) / per_block;
   if (b > cap) b = cap;
@@ -367,6 +684,33 @@ extern "C" int dcc_im2col3d(const float* x, void* col, int B, int T, int H, int 
   return dcc_check_launch();
 }
 
+template <typename T, typename TD, int S, bool MIRROR>
+int launch_dw3_run(const void* x, void* y, const float* w, const PoolGeom& g, hipStream_t s) {
+  constexpr int vec = Vec16<T>::N;
+  const int cpr = g.C / vec;
+  // runs of 7 output columns when the grid allows (56/28/14/7) and still leaves >= 2 waves per SIMD, else runs of 4
+  const int64_t threads7 = (int64_t)g.B * g.H * g.To * g.Ho * ((g.Wo + 6) / 7) * cpr;
+  const bool w7 = (g.Wo % 7 == 0) && threads7 >= 131072;
+  const RunGeom r = make_run_geom(g, vec, w7 ? 7 : 4);
+  const int items = r.runs + (g.has_cls ? g.B * g.H : 0);
+  const dim3 grid((items + r.slots - 1) / r.slots);
+  const size_t lds = (size_t)27 * g.C * 4;
+  if (w7) hipLaunchKernelGGL((dw3_run_kernel<T, TD, S, 7, MIRROR>), grid, dim3(256), lds, s, (const TD*)x, (T*)y, w, r);
+  else hipLaunchKernelGGL((dw3_run_kernel<T, TD, S, 4, MIRROR>), grid, dim3(256), lds, s, (const TD*)x, (T*)y, w, r);
+  return dcc_check_launch();
+}
+
+template <typename T, typename TD, bool MIRROR>
+int launch_dw3_run_s(int S, const void* x, void* y, const float* w, const PoolGeom& g, hipStream_t s) {
+  if (S == 1) return launch_dw3_run<T, TD, 1, MIRROR>(x, y, w, g, s);
+  if constexpr (!MIRROR) {
+    if (S == 2) return launch_dw3_run<T, TD, 2, false>(x, y, w, g, s);
+    if (S == 4) return launch_dw3_run<T, TD, 4, false>(x, y, w, g, s);
+    if (S == 8) return launch_dw3_run<T, TD, 8, false>(x, y, w, g, s);
+  }
+  return DCC_ERR_UNSUPPORTED;
+}
+
 // dims: [B,H,C,T,Hs,Ws,kt,kh,kw,st,sh,sw,pt,ph,pw,has_cls]; strides: [sxb,sxn,sxh,syb,syn,syh]
 // mode 0 = depthwise conv (w = [C][kt*kh*kw] fp32), mode 1 = max pool (argmax uint8 [B,No,H,C] or null)
 extern "C" int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* argmax, const int* dims,
@@ -376,10 +720,17 @@ extern "C" int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* arg
   const int vec = dtype == DCC_BF16 ? 8 : 4;
   int rc = geom_ok(g, vec);
   if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) {
+    // measured (scratch/pool_bench.py): the run kernel wins for stride 1; strided pools read each input at most
+    // once already and are faster with one output per thread
+    const int S = dw3_stride(g, vec);
+    if (S == 1 && dtype == DCC_BF16) return launch_dw3_run_s<bf16_t, bf16_t, false>(S, x, y, w, g, s);
+    if (S == 1 && dtype == DCC_F32) return launch_dw3_run_s<float, float, false>(S, x, y, w, g, s);
+  }
   const int64_t total = (int64_t)g.B * (g.To * g.Ho * g.Wo + g.has_cls) * g.H * (g.C / vec);
   dim3 grid(blocks_for(total, 256, 8192));
   const size_t lds = mode == 0 ? (size_t)g.kt * g.kh * g.kw * g.C * 4 : 0;
-  hipStream_t s = (hipStream_t)stream;
   if (dtype == DCC_BF16) {
     if (mode == 0) hipLaunchKernelGGL((pool_fwd_kernel<bf16_t, false>), grid, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, w, argmax, g);
     else hipLaunchKernelGGL((pool_fwd_kernel<bf16_t, true>), grid, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, w, argmax, g);
@@ -398,10 +749,33 @@ extern "C" int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const
   const int vec = dtype == DCC_BF16 ? 8 : 4;
   int rc = geom_ok(g, vec);
   if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) {
+    const int S = dw3_stride(g, vec);
+    if (S == 1) {
+      // stride 1: the mirrored stencil over dy; the run kernel reads through the x-strides and writes through the y-strides
+      PoolGeom m = g;
+      m.sxb = g.syb; m.sxn = g.syn; m.sxh = g.syh; m.syb = g.sxb; m.syn = g.sxn; m.syh = g.sxh;
+      if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) return launch_dw3_run_s<bf16_t, bf16_t, true>(1, dy, dx, w, m, s);
+      if (dtype == DCC_BF16 && grad_dtype == DCC_F32) return launch_dw3_run_s<bf16_t, float, true>(1, dy, dx, w, m, s);
+      if (dtype == DCC_F32 && grad_dtype == DCC_F32) return launch_dw3_run_s<float, float, true>(1, dy, dx, w, m, s);
+    } else if (S > 1) {
+      const RunGeom r = make_run_geom(g, vec, 4);
+      const int items = g.B * g.H * g.T * g.Hs * g.Ws + (g.has_cls ? g.B * g.H : 0);
+      const dim3 grid((items + r.slots - 1) / r.slots);
+      const size_t lds3 = (size_t)27 * g.C * 4;
+#define DW3S(T_, TD_, S_) hipLaunchKernelGGL((dw3_bwd_data_strided_kernel<T_, TD_, S_>), grid, dim3(256), lds3, s, (const TD_*)dy, (T_*)dx, w, r)
+#define DW3S_ALL(T_, TD_) do { if (S == 2) DW3S(T_, TD_, 2); else if (S == 4) DW3S(T_, TD_, 4); else DW3S(T_, TD_, 8); return dcc_check_launch(); } while (0)
+      if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) DW3S_ALL(bf16_t, bf16_t);
+      if (dtype == DCC_BF16 && grad_dtype == DCC_F32) DW3S_ALL(bf16_t, float);
+      if (dtype == DCC_F32 && grad_dtype == DCC_F32) DW3S_ALL(float, float);
+#undef DW3S_ALL
+#undef DW3S
+    }
+  }
   const int64_t total = (int64_t)g.B * (g.T * g.Hs * g.Ws + g.has_cls) * g.H * (g.C / vec);
   dim3 grid(blocks_for(total, 256, 8192));
   const size_t lds = mode == 0 ? (size_t)g.kt * g.kh * g.kw * g.C * 4 : 0;
-  hipStream_t s = (hipStream_t)stream;
 #define PBD(T_, TD_, MP) hipLaunchKernelGGL((pool_bwd_data_kernel<T_, TD_, MP>), grid, dim3(256), lds, s, (const TD_*)dy, (T_*)dx, w, argmax, g)
   if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) { if (mode == 0) PBD(bf16_t, bf16_t, false); else PBD(bf16_t, bf16_t, true); }
   else if (dtype == DCC_BF16 && grad_dtype == DCC_F32) { if (mode == 0) PBD(bf16_t, float, false); else PBD(bf16_t, float, true); }
@@ -418,6 +792,48 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
   PoolGeom g = make_geom(dims, strides);
   int rc = geom_ok(g, dtype == DCC_BF16 ? 8 : 4);
   if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  {
+    const int vec = dtype == DCC_BF16 ? 8 : 4;
+    const int S = dw3_stride(g, vec);
+    if (S && (256 / (g.C / vec)) >= 3) {
+      const bool w7 = (g.Wo % 7 == 0);
+      const RunGeom r = make_run_geom(g, vec, w7 ? 7 : 4);
+      const int slots3 = r.slots / 3;
+      const int total_iters = (r.runs + slots3 - 1) / slots3;
+      int nblocks = total_iters < 512 ? total_iters : 512;  // <= DCC_DWCONV_WS_BLOCKS; two 75-KB blocks per CU
+      if (nblocks < 1) nblocks = 1;
+      const int iters = (total_iters + nblocks - 1) / nblocks;
+      nblocks = (total_iters + iters - 1) / iters;
+      const size_t lds3 = (size_t)256 * (9 * vec + 1) * 4;
+#define DW3W(T_, TD_, S_, W_)                                                                                       \
+  do {                                                                                                              \
+    auto kern = dw3_wgrad_kernel<T_, TD_, S_, W_>;                                                                  \
+    static bool cfg = false;                                                                                        \
+    if (!cfg) {                                                                                                     \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess) return DCC_ERR_LAUNCH; \
+      cfg = true;                                                                                                   \
+    }                                                                                                               \
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds3, s, (const TD_*)dy, (const T_*)x, workspace, r, iters); \
+  } while (0)
+#define DW3W_S(T_, TD_, W_) do { if (S == 1) DW3W(T_, TD_, 1, W_); else if (S == 2) DW3W(T_, TD_, 2, W_); else if (S == 4) DW3W(T_, TD_, 4, W_); else DW3W(T_, TD_, 8, W_); } while (0)
+#define DW3W_ALL(T_, TD_) do { if (w7) DW3W_S(T_, TD_, 7); else DW3W_S(T_, TD_, 4); } while (0)
+      bool done = true;
+      if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) DW3W_ALL(bf16_t, bf16_t);
+      else if (dtype == DCC_BF16 && grad_dtype == DCC_F32) DW3W_ALL(bf16_t, float);
+      else if (dtype == DCC_F32 && grad_dtype == DCC_F32) DW3W_ALL(float, float);
+      else done = false;
+#undef DW3W_ALL
+#undef DW3W_S
+#undef DW3W
+      if (done) {
+        rc = dcc_check_launch();
+        if (rc) return rc;
+        hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((27 * g.C + 31) / 32), dim3(256), 0, s, workspace, dw, nblocks, 27, g.C);
+        return dcc_check_launch();
+      }
+    }
+  }
   const int cv = dtype == DCC_BF16 ? 8 : 4;
   if (g.C % cv || g.C / cv > 85) return DCC_ERR_UNSUPPORTED;
   const int slots = (256 / (g.C / cv)) / 3 * 3;
@@ -426,7 +842,6 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
   const int64_t total = (int64_t)g.B * g.H * g.To * g.Ho * g.Wo * 3;
   dim3 grid(blocks_for(total, slots * 4, 1024));  // <= DCC_DWCONV_WS_BLOCKS
   const size_t lds = (size_t)taps * g.C * 4;
-  hipStream_t s = (hipStream_t)stream;
   if (dtype == DCC_BF16 && grad_dtype == DCC_BF16)
     hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, workspace, g);
   else if (dtype == DCC_BF16 && grad_dtype == DCC_F32)
