@@ -5,6 +5,7 @@
 // Tokens are [B, N, H, C] views (strides in elements, C contiguous); token 0 is the class token
 // when has_cls != 0 and bypasses the pooling; the remaining tokens form a (T, Hs, Ws) grid.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -339,6 +340,25 @@ struct RunGeom {
   FastDiv d_cpr, d_runsW, d_Ho, d_To, d_H, d_Ws, d_Hs, d_T;
 };
 
+// raw (unconverted) CV-element vector: issue all loads of a phase first, convert when consumed
+template <typename TD, int CV> struct RawCV { f32x4 q[sizeof(TD) * CV / 16]; };
+template <typename TD, int CV> __device__ __forceinline__ RawCV<TD, CV> load_raw(const TD* p) {
+  RawCV<TD, CV> r;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(TD) * CV / 16); ++i) r.q[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p) + 16 * i);
+  return r;
+}
+template <typename TD, int CV> __device__ __forceinline__ void raw_to_f32(const RawCV<TD, CV>& r, float* f) {
+  if constexpr (sizeof(TD) == 2) {
+    const bf16x8 v = __builtin_bit_cast(bf16x8, r.q[0]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+  } else {
+#pragma unroll
+    for (int i = 0; i < CV / 4; ++i) { f[4 * i] = r.q[i][0]; f[4 * i + 1] = r.q[i][1]; f[4 * i + 2] = r.q[i][2]; f[4 * i + 3] = r.q[i][3]; }
+  }
+}
+
 template <typename TD, int CV> __device__ __forceinline__ void load_cv(const TD* p, float* f) {
   if constexpr (sizeof(TD) == 2) {
     static_assert(CV == 8, "bf16 chunks are 8 wide");
@@ -416,16 +436,39 @@ __global__ __launch_bounds__(256) void dw3_run_kernel(const TD* __restrict__ x, 
   for (int i = 0; i < WT; ++i)
 #pragma unroll
     for (int e = 0; e < CV; ++e) acc[i][e] = 0.0f;
+  // Branch-free: coordinates are clamped for the address and the tap weight is zeroed instead, so that all loads of a
+  // temporal slab (3 rows x SEG columns) are in flight together — the kernel is bound by memory latency, not by
+  // instruction count.
   const int col0 = p.w0 * S - 1;
+  int coff[SEG];
+  bool cok[SEG];
 #pragma unroll
-  for (int kt = 0; kt < 3; ++kt) {
+  for (int j = 0; j < SEG; ++j) {
+    const int col = col0 + j;
+    cok[j] = col >= 0 && col < g.Ws;
+    coff[j] = col < 0 ? 0 : (col >= g.Ws ? g.Ws - 1 : col);
+  }
+#pragma unroll 1
+  for (int kt = 0; kt < 3; ++kt) {  // rolled: one slab of loads in flight is what the register file holds
     const int t = p.to + kt - 1;
-    if (t < 0 || t >= g.T) continue;
+    const bool tok = t >= 0 && t < g.T;
+    const int tc = t < 0 ? 0 : (t >= g.T ? g.T - 1 : t);
+    RawCV<TD, CV> raw[3][SEG];
+    bool rok[3];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int hh = p.ho * S + kh - 1;
-      if (hh < 0 || hh >= g.Hs) continue;
-      const TD* row = xb + (int64_t)(g.has_cls + (t * g.Hs + hh) * g.Ws) * g.sxn;
+      rok[kh] = tok && hh >= 0 && hh < g.Hs;
+      const int hc = hh < 0 ? 0 : (hh >= g.Hs ? g.Hs - 1 : hh);
+      const TD* row = xb + (int64_t)(g.has_cls + (tc * g.Hs + hc) * g.Ws) * g.sxn;
+#pragma unroll
+      for (int j = 0; j < SEG; ++j) {
+        if (S > 2 && (j % S) > 2) continue;  // columns between the windows of a wide stride are never used
+        raw[kh][j] = load_raw<TD, CV>(row + (int64_t)coff[j] * g.sxn);
+      }
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
       float wt[3][CV];
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
@@ -433,17 +476,17 @@ __global__ __launch_bounds__(256) void dw3_run_kernel(const TD* __restrict__ x, 
 #pragma unroll
         for (int q = 0; q < CV / 4; ++q) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(wp + 4 * q);
-          wt[kw][4 * q] = v[0]; wt[kw][4 * q + 1] = v[1]; wt[kw][4 * q + 2] = v[2]; wt[kw][4 * q + 3] = v[3];
+          wt[kw][4 * q] = rok[kh] ? v[0] : 0.0f; wt[kw][4 * q + 1] = rok[kh] ? v[1] : 0.0f;
+          wt[kw][4 * q + 2] = rok[kh] ? v[2] : 0.0f; wt[kw][4 * q + 3] = rok[kh] ? v[3] : 0.0f;
         }
       }
 #pragma unroll
       for (int j = 0; j < SEG; ++j) {
-        if (S > 2 && (j % S) > 2) continue;  // columns between the windows of a wide stride are never used
-        const int col = col0 + j;
+        if (S > 2 && (j % S) > 2) continue;
         float f[CV];
+        raw_to_f32<TD, CV>(raw[kh][j], f);
 #pragma unroll
-        for (int e = 0; e < CV; ++e) f[e] = 0.0f;
-        if (col >= 0 && col < g.Ws) load_cv<TD, CV>(row + (int64_t)col * g.sxn, f);
+        for (int e = 0; e < CV; ++e) f[e] = cok[j] ? f[e] : 0.0f;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           if ((j - kw) >= 0 && (j - kw) % S == 0 && (j - kw) / S < WT) {
@@ -560,30 +603,53 @@ __global__ __launch_bounds__(256) void dw3_wgrad_kernel(const TD* __restrict__ d
       if ((int)run >= r.runs) break;
       const RunPos p = run_pos(run, r, WT);
       const int t = p.to + kt - 1;
-      if (t < 0 || t >= g.T) continue;
-      float dv[WT][CV];
+      const bool tok = t >= 0 && t < g.T;
+      const int tc = t < 0 ? 0 : (t >= g.T ? g.T - 1 : t);
+      // branch-free: every load of the run (WT dy chunks + 3 input row segments) is issued before the first FMA
+      RawCV<TD, CV> draw[WT];
       const TD* dyb = dy + p.b * g.syb + p.hd * g.syh + c * CV + (int64_t)(g.has_cls + (p.to * g.Ho + p.ho) * g.Wo) * g.syn;
 #pragma unroll
       for (int i = 0; i < WT; ++i) {
-#pragma unroll
-        for (int e = 0; e < CV; ++e) dv[i][e] = 0.0f;
-        if (p.w0 + i < g.Wo) load_cv<TD, CV>(dyb + (int64_t)(p.w0 + i) * g.syn, dv[i]);
+        const int wo = p.w0 + i < g.Wo ? p.w0 + i : g.Wo - 1;
+        draw[i] = load_raw<TD, CV>(dyb + (int64_t)wo * g.syn);
       }
       const T* xb = x + p.b * g.sxb + p.hd * g.sxh + c * CV;
       const int col0 = p.w0 * S - 1;
+      RawCV<T, CV> raw[3][SEG];
+      bool rok[3];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int hh = p.ho * S + kh - 1;
-        if (hh < 0 || hh >= g.Hs) continue;
-        const T* row = xb + (int64_t)(g.has_cls + (t * g.Hs + hh) * g.Ws) * g.sxn;
+        rok[kh] = tok && hh >= 0 && hh < g.Hs;
+        const int hc = hh < 0 ? 0 : (hh >= g.Hs ? g.Hs - 1 : hh);
+        const T* row = xb + (int64_t)(g.has_cls + (tc * g.Hs + hc) * g.Ws) * g.sxn;
 #pragma unroll
         for (int j = 0; j < SEG; ++j) {
           if (S > 2 && (j % S) > 2) continue;
           const int col = col0 + j;
-          float f[CV];
+          const int cc = col < 0 ? 0 : (col >= g.Ws ? g.Ws - 1 : col);
+          raw[kh][j] = load_raw<T, CV>(row + (int64_t)cc * g.sxn);
+        }
+      }
+      float dv[WT][CV];
 #pragma unroll
-          for (int e = 0; e < CV; ++e) f[e] = 0.0f;
-          if (col >= 0 && col < g.Ws) load_cv<T, CV>(row + (int64_t)col * g.sxn, f);
+      for (int i = 0; i < WT; ++i) {
+        raw_to_f32<TD, CV>(draw[i], dv[i]);
+        const bool ok = p.w0 + i < g.Wo;
+#pragma unroll
+        for (int e = 0; e < CV; ++e) dv[i][e] = ok ? dv[i][e] : 0.0f;
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) {
+          if (S > 2 && (j % S) > 2) continue;
+          const int col = col0 + j;
+          const bool ok = rok[kh] && col >= 0 && col < g.Ws;
+          float f[CV];
+          raw_to_f32<T, CV>(raw[kh][j], f);
+#pragma unroll
+          for (int e = 0; e < CV; ++e) f[e] = ok ? f[e] : 0.0f;
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
             if ((j - kw) >= 0 && (j - kw) % S == 0 && (j - kw) / S < WT) {
@@ -690,7 +756,8 @@ int launch_dw3_run(const void* x, void* y, const float* w, const PoolGeom& g, hi
   const int cpr = g.C / vec;
   // runs of 7 output columns when the grid allows (56/28/14/7) and still leaves >= 2 waves per SIMD, else runs of 4
   const int64_t threads7 = (int64_t)g.B * g.H * g.To * g.Ho * ((g.Wo + 6) / 7) * cpr;
-  const bool w7 = (g.Wo % 7 == 0) && threads7 >= 131072;
+  bool w7 = (g.Wo % 7 == 0) && threads7 >= 131072;
+  if (const char* e = getenv("DCC_POOL_WT")) w7 = w7 && atoi(e) == 7;  // A/B knob for scratch/pool_bench.py
   const RunGeom r = make_run_geom(g, vec, w7 ? 7 : 4);
   const int items = r.runs + (g.has_cls ? g.B * g.H : 0);
   const dim3 grid((items + r.slots - 1) / r.slots);
