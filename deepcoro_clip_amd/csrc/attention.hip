@@ -517,29 +517,41 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
-// Dv[b,h,q] = sum_d dO[q][d] * (O[q][d] - [q >= res_start] Qres[q][d]); one wave per (b,h,q) row.
+// Dv[b,h,q] = sum_d dO[q][d] * (O[q][d] - [q >= res_start] Qres[q][d]).  16 lanes per (b,h,q) row, 16-byte chunks
+// (rows are 96..128 wide: 12..16 lanes carry data), folded with four shuffles.
 template <typename T>
-__global__ void attn_bwd_prep_kernel(AttnParams p, int DV) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnParams p, int DV) {
+  constexpr int VEC = Vec16<T>::N;
+  using V = vec16_t<T>;
+  const int sub = threadIdx.x & 15;
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int64_t total = (int64_t)p.B * p.H * p.Nq;
-  if (row >= total) return;
-  const int q = row % p.Nq;
-  const int hd = (row / p.Nq) % p.H;
-  const int b = row / ((int64_t)p.Nq * p.H);
-  const T* o = reinterpret_cast<const T*>(p.O) + b * p.sob + hd * p.soh + (int64_t)q * p.son;
-  const T* d = reinterpret_cast<const T*>(p.dO) + b * p.sob + hd * p.soh + (int64_t)q * p.son;
-  const T* r = (p.Qres && q >= p.res_start)
-                   ? reinterpret_cast<const T*>(p.Qres) + b * p.sqb + hd * p.sqh + (int64_t)q * p.sqn
-                   : nullptr;
   float acc = 0.0f;
-  for (int c = lane; c < DV; c += 64) {
-    float ov = to_f32(o[c]);
-    if (r) ov -= to_f32(r[c]);
-    acc += to_f32(d[c]) * ov;
+  if (row < total) {
+    const int q = row % p.Nq;
+    const int hd = (row / p.Nq) % p.H;
+    const int b = row / ((int64_t)p.Nq * p.H);
+    const T* o = reinterpret_cast<const T*>(p.O) + b * p.sob + hd * p.soh + (int64_t)q * p.son;
+    const T* d = reinterpret_cast<const T*>(p.dO) + b * p.sob + hd * p.soh + (int64_t)q * p.son;
+    const T* r = (p.Qres && q >= p.res_start)
+                     ? reinterpret_cast<const T*>(p.Qres) + b * p.sqb + hd * p.sqh + (int64_t)q * p.sqn
+                     : nullptr;
+    for (int c = sub * VEC; c < DV; c += 16 * VEC) {
+      const V ov = *reinterpret_cast<const V*>(o + c);
+      const V dv = *reinterpret_cast<const V*>(d + c);
+      if (r) {
+        const V rv = *reinterpret_cast<const V*>(r + c);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc += to_f32(dv[e]) * (to_f32(ov[e]) - to_f32(rv[e]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc += to_f32(dv[e]) * to_f32(ov[e]);
+      }
+    }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) const_cast<float*>(p.Dv)[row] = acc;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (sub == 0 && row < total) const_cast<float*>(p.Dv)[row] = acc;
 }
 
 template <typename T, int DQK, int DV>
@@ -625,10 +637,9 @@ extern "C" int dcc_attn_bwd(const void* Q, const void* K, const void* V, const v
     if (strides[i] % 4) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * H * Nq;
-  const int wpb = 4;
-  dim3 pg((unsigned)((rows + wpb - 1) / wpb));
-  if (dtype == DCC_BF16) hipLaunchKernelGGL((attn_bwd_prep_kernel<bf16_t>), pg, dim3(64 * wpb), 0, st, p, DV);
-  else if (dtype == DCC_F32) hipLaunchKernelGGL((attn_bwd_prep_kernel<float>), pg, dim3(64 * wpb), 0, st, p, DV);
+  dim3 pg((unsigned)((rows + 15) / 16));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((attn_bwd_prep_kernel<bf16_t>), pg, dim3(256), 0, st, p, DV);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((attn_bwd_prep_kernel<float>), pg, dim3(256), 0, st, p, DV);
   else return DCC_ERR_UNSUPPORTED;
   rc = dcc_check_launch();
   if (rc) return rc;
