@@ -48,7 +48,7 @@ def build_job(args, device, world, rank):
     torch.manual_seed(0)  # same random-init weights on every rank
     ve = VideoEncoder(backbone="mvit", num_frames=args.frames, spatial_size=(args.size, args.size), pretrained=False,
                       freeze_ratio=1.0, dropout=0.0, token_pooling_mode=args.pooling, attention_pool_dropout=0.0,
-                      compute_dtype=dtype).to(device)
+                      compute_dtype=dtype, stochastic_depth_prob=0.0).to(device)  # dropout 0, stochastic depth 0
     te = TextEncoder(dropout=0.0, freeze_ratio=0.0, compute_dtype=dtype,
                      bert_config=dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).to(device)
     ve.train()

@@ -63,6 +63,29 @@ __global__ void axpby_kernel(T* __restrict__ out, float a, const T* __restrict__
   }
 }
 
+// out[r][c] = resid[r][c] + x[r][c] * scale[r / rows_per_sample]   (stochastic depth "row" mode: one Bernoulli
+// keep/(1-p) factor per clip; resid may be null -> the backward's d_branch = dout * scale)
+template <typename T>
+__global__ void scale_rows_kernel(const T* __restrict__ x, const float* __restrict__ scale, const T* __restrict__ resid,
+                                  T* __restrict__ out, int64_t n8, int64_t per_sample8) {
+  constexpr int VEC = Vec16<T>::N;
+  using V = vec16_t<T>;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const float sc = scale[i / per_sample8];
+    const V xv = *reinterpret_cast<const V*>(x + i * VEC);
+    V o;
+    if (resid) {
+      const V rv = *reinterpret_cast<const V*>(resid + i * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(to_f32(rv[e]) + to_f32(xv[e]) * sc);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(to_f32(xv[e]) * sc);
+    }
+    *reinterpret_cast<V*>(out + i * VEC) = o;
+  }
+}
+
 // out = dy * gelu'(pre)
 template <typename T>
 __global__ void dgelu_mul_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ out, int64_t n) {
@@ -320,6 +343,19 @@ extern "C" int dcc_axpby(void* out, float a, const void* x, float b, const void*
   dim3 g(gs_blocks(n, 4));
   if (dtype == DCC_BF16) hipLaunchKernelGGL((axpby_kernel<bf16_t>), g, dim3(256), 0, ST, (bf16_t*)out, a, (const bf16_t*)x, b, (const bf16_t*)y, n);
   else if (dtype == DCC_F32) hipLaunchKernelGGL((axpby_kernel<float>), g, dim3(256), 0, ST, (float*)out, a, (const float*)x, b, (const float*)y, n);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_scale_rows(const void* x, const float* scale, const void* resid, void* out, int64_t samples,
+                              int64_t per_sample, int dtype, void* stream) {
+  if (!x || !scale || !out || samples <= 0 || per_sample <= 0) return DCC_ERR_ARG;
+  const int vec = dtype == DCC_BF16 ? 8 : 4;
+  if ((per_sample % vec) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)resid & 15)) return DCC_ERR_UNSUPPORTED;
+  const int64_t n8 = samples * per_sample / vec;
+  dim3 g(gs_blocks(n8, 2));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((scale_rows_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, scale, (const bf16_t*)resid, (bf16_t*)out, n8, per_sample / vec);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((scale_rows_kernel<float>), g, dim3(256), 0, ST, (const float*)x, scale, (const float*)resid, (float*)out, n8, per_sample / vec);
   else return DCC_ERR_UNSUPPORTED;
   return dcc_check_launch();
 }

@@ -511,6 +511,63 @@ def add(a, b):
     return AddFn.apply(a, b)
 
 
+class StochasticDepthFn(torch.autograd.Function):
+    """out = resid + branch * scale[sample]  (torchvision StochasticDepth, mode "row", fused with the residual add)."""
+
+    @staticmethod
+    def forward(ctx, resid, branch, scale, samples):
+        ctx.save_for_backward(scale)
+        ctx.samples = samples
+        return K.scale_rows(_c(branch), scale, samples, resid=_c(resid))
+
+    @staticmethod
+    def backward(ctx, d):
+        (scale,) = ctx.saved_tensors
+        d = _c(d)
+        return d, K.scale_rows(d, scale, ctx.samples), None, None
+
+
+def stochastic_depth_add(resid, branch, p: float, samples: int):
+    """resid + StochasticDepth(p, "row")(branch) in training mode (caller handles eval / p == 0 with the fused
+    GEMM residual instead).  One Bernoulli(1-p)/(1-p) factor per clip, drawn from torch's device generator."""
+    keep = 1.0 - p
+    scale = torch.bernoulli(torch.full((samples,), keep, device=branch.device, dtype=torch.float32)) / keep
+    return StochasticDepthFn.apply(resid, branch, scale, samples)
+
+
+class InterpRowsFn(torch.autograd.Function):
+    """table' = W table with a fixed [d, L] interpolation matrix (torchvision mvit._interpolate: F.interpolate(linear,
+    align_corners=False) of a relative-position table whose length does not match the token grid)."""
+
+    @staticmethod
+    def forward(ctx, table, W):
+        ctx.save_for_backward(W)
+        return K.gemm(W, _c(table.detach()).float(), b_km=True)  # [d, L] x [L, C]
+
+    @staticmethod
+    def backward(ctx, d):
+        (W,) = ctx.saved_tensors
+        return K.gemm(W, _c(d).float(), a_km=True, b_km=True), None  # W^T d: [L, d] x [d, C]
+
+
+def interp_matrix(length_in: int, length_out: int) -> torch.Tensor:
+    """Rows of F.interpolate(mode="linear", align_corners=False): out[i] = (1-l) in[i0] + l in[i1]."""
+    W = torch.zeros(length_out, length_in, dtype=torch.float32)
+    scale = length_in / length_out
+    for i in range(length_out):
+        src = max((i + 0.5) * scale - 0.5, 0.0)
+        i0 = min(int(src), length_in - 1)
+        i1 = min(i0 + 1, length_in - 1)
+        lam = src - i0
+        W[i, i0] += 1.0 - lam
+        W[i, i1] += lam
+    return W
+
+
+def interp_rows(table, W):
+    return InterpRowsFn.apply(table, W)
+
+
 class CastFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dtype):

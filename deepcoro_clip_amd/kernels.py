@@ -406,6 +406,17 @@ def axpby(x: torch.Tensor, y: torch.Tensor | None = None, a: float = 1.0, b: flo
     return out
 
 
+def scale_rows(x: torch.Tensor, scale: torch.Tensor, samples: int, resid: torch.Tensor | None = None) -> torch.Tensor:
+    """out = resid + x * scale[sample]; x is [samples * rows, C] with equally many rows per sample."""
+    L.require_cuda(x, scale, resid)
+    assert x.is_contiguous() and scale.dtype == torch.float32 and scale.numel() == samples and x.numel() % samples == 0
+    assert resid is None or (resid.is_contiguous() and resid.shape == x.shape and resid.dtype == x.dtype)
+    out = torch.empty_like(x)
+    L.call("dcc_scale_rows", L.ptr(x), L.ptr(scale), L.ptr(resid), L.ptr(out), samples, x.numel() // samples, L.dt(x),
+           L.stream())
+    return out
+
+
 def dgelu_mul(dy: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:
     L.require_cuda(dy, pre)
     assert dy.is_contiguous() and pre.is_contiguous() and dy.shape == pre.shape and dy.dtype == pre.dtype

@@ -79,11 +79,12 @@ class _Attention(nn.Module):
 
 
 class _Block(nn.Module):
-    def __init__(self, p, eps):
+    def __init__(self, p, eps, sd_prob: float = 0.0):
         super().__init__()
         cin, cout = p["in_ch"], p["out_ch"]
         self.p = p
         self.eps = eps
+        self.sd_prob = float(sd_prob)  # torchvision StochasticDepth(sd_prob, "row") on both residual branches
         self.norm1 = nn.LayerNorm(cin, eps=eps)
         self.norm2 = nn.LayerNorm(cout, eps=eps)
         self.attn = _Attention(p, eps)
@@ -93,25 +94,24 @@ class _Block(nn.Module):
         self._idx_cache: dict = {}
 
     def _idx(self, device):
-        """(idx, inv) device tables: idx_a[q][k] = table row of a (query coord, key coord) pair, inv_a[q][l] = the key
-        coord whose pair uses row l (or -1)."""
+        """(idx, inv, interp) device tables: idx_a[q][k] = table row of a (query coord, key coord) pair, inv_a[q][l] =
+        the key coord whose pair uses row l (or -1), interp_a = [d, L] resampling matrix when the stored table length L
+        differs from d = 2 max(q, k) - 1 (torchvision mvit._interpolate: grids that are not multiples of their
+        strides, e.g. 112 x 112 inputs), else None."""
         key = str(device)
         if key not in self._idx_cache:
             p = self.p
-            idx, inv = [], []
+            idx, inv, interp = [], [], []
             for a, table in ((1, self.attn.rel_pos_h), (2, self.attn.rel_pos_w), (0, self.attn.rel_pos_t)):
                 qs, ks = p["q_thw"][a], p["k_thw"][a]
-                if table.shape[0] != 2 * max(qs, ks) - 1:
-                    raise NotImplementedError(
-                        "relative-position table interpolation (input size not a multiple of 32 / odd frame pairs) "
-                        f"is not implemented on the HIP path yet: block {p['index']} table {table.shape[0]} vs "
-                        f"grid q={qs} k={ks}")
+                d = 2 * max(qs, ks) - 1
+                interp.append(None if table.shape[0] == d else Fn.interp_matrix(table.shape[0], d).to(device))
                 ix = Fn.relpos_index(qs, ks)
-                iv = torch.full((qs, table.shape[0]), -1, dtype=torch.int32)
+                iv = torch.full((qs, d), -1, dtype=torch.int32)
                 iv.scatter_(1, ix.long(), torch.arange(ks, dtype=torch.int32).expand(qs, ks).contiguous())
                 idx.append(ix.to(device))
                 inv.append(iv.contiguous().to(device))
-            self._idx_cache[key] = (tuple(idx), tuple(inv))
+            self._idx_cache[key] = (tuple(idx), tuple(inv), tuple(interp))
         return self._idx_cache[key]
 
     def forward_tokens(self, x, Bp, rope=None):
@@ -121,20 +121,28 @@ class _Block(nn.Module):
         N = x.shape[0] // Bp
         xn1 = Fn.layernorm(x, self.norm1.weight, self.norm1.bias, self.eps)
         qkv = Fn.linear(xn1, a.qkv.weight, a.qkv.bias)
+        idx, inv, interp = self._idx(x.device)
         cfg = dict(B=Bp, N=N, H=a.num_heads, D=hd, thw=p["thw"], eps=self.eps, stride_q=p["stride_q"],
-                   stride_kv=p["stride_kv"], scale=1.0 / math.sqrt(hd), idx=self._idx(x.device)[0],
-                   inv=self._idx(x.device)[1], rope=rope)
+                   stride_kv=p["stride_kv"], scale=1.0 / math.sqrt(hd), idx=idx, inv=inv, rope=rope)
+        rel = [t if w is None else Fn.interp_rows(t, w) for t, w in zip((a.rel_pos_h, a.rel_pos_w, a.rel_pos_t), interp)]
         att = Fn.mvit_attention_core(
             qkv, a.pool_q.pool.weight, a.pool_k.pool.weight, a.pool_v.pool.weight,
             a.pool_q.norm_act[0].weight, a.pool_q.norm_act[0].bias, a.pool_k.norm_act[0].weight,
             a.pool_k.norm_act[0].bias, a.pool_v.norm_act[0].weight, a.pool_v.norm_act[0].bias,
-            a.rel_pos_h, a.rel_pos_w, a.rel_pos_t, cfg)
+            rel[0], rel[1], rel[2], cfg)
         xs = x if self.project is None else Fn.linear(xn1, self.project.weight, self.project.bias)
         if math.prod(p["stride_q"]) > 1:
             ks = tuple(s + 1 if s > 1 else s for s in p["stride_q"])
             xs = Fn.pool_skip(xs, Bp, p["thw"], ks, p["stride_q"], tuple(k // 2 for k in ks))
-        x = Fn.linear(att, a.project[0].weight, a.project[0].bias, residual=xs)
+        drop = self.training and self.sd_prob > 0.0
+        if drop:  # x = skip + sd(attn); x = x + sd(mlp): the residual add moves out of the GEMM epilogue
+            x = Fn.stochastic_depth_add(xs, Fn.linear(att, a.project[0].weight, a.project[0].bias), self.sd_prob, Bp)
+        else:
+            x = Fn.linear(att, a.project[0].weight, a.project[0].bias, residual=xs)
         xn2 = Fn.layernorm(x, self.norm2.weight, self.norm2.bias, self.eps)
+        if drop:
+            return Fn.stochastic_depth_add(x, Fn.mlp(xn2, self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight,
+                                                     self.mlp[3].bias), self.sd_prob, Bp)
         return Fn.mlp(xn2, self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight, self.mlp[3].bias, residual=x)
 
 
@@ -169,12 +177,14 @@ def rope_tables(T, H, W, head_dim, base=10000.0, temporal_scale=1.0, n_special=1
 class HipMViT(nn.Module):
     """Size-parameterised MViT-v2-S (head = Identity): `forward_features` returns all tokens incl. the class token."""
 
-    def __init__(self, temporal_size: int = 16, spatial_size: Sequence[int] = (224, 224), eps: float = 1e-6):
+    def __init__(self, temporal_size: int = 16, spatial_size: Sequence[int] = (224, 224), eps: float = 1e-6,
+                 stochastic_depth_prob: float = 0.2):
         super().__init__()
         self.plan = block_plan(temporal_size, spatial_size)
         self.conv_proj = nn.Conv3d(3, 96, kernel_size=(3, 7, 7), stride=(2, 4, 4), padding=(1, 3, 3))
         self.pos_encoding = _PosEnc(96, temporal_size // 2, (spatial_size[0] // 4, spatial_size[1] // 4))
-        self.blocks = nn.ModuleList([_Block(p, eps) for p in self.plan])
+        # torchvision: sd_prob grows linearly over the 16 blocks, 0 -> stochastic_depth_prob (mvit_v2_s: 0.2)
+        self.blocks = nn.ModuleList([_Block(p, eps, stochastic_depth_prob * i / 15.0) for i, p in enumerate(self.plan)])
         self.norm = nn.LayerNorm(768, eps=eps)
         self.head = nn.Identity()
         self.eps = eps

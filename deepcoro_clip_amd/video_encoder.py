@@ -49,6 +49,7 @@ class VideoEncoder(nn.Module):
         encoder_path: Optional[str] = None,
         spatial_size: tuple[int, int] = (224, 224),
         compute_dtype: torch.dtype = torch.bfloat16,
+        stochastic_depth_prob: float = 0.2,
     ):
         super().__init__()
         self.backbone = backbone
@@ -69,7 +70,9 @@ class VideoEncoder(nn.Module):
             if input_channels != 3:
                 raise ValueError("the MViT patch embedding takes 3 input channels")
             # the reference ignores num_frames for mvit (torchvision default 16); here it sizes the trunk
-            self.model: nn.Module = HipMViT(temporal_size=num_frames, spatial_size=spatial_size)
+            # stochastic_depth_prob 0.2 = torchvision's mvit_v2_s default, which the reference trains with
+            self.model: nn.Module = HipMViT(temporal_size=num_frames, spatial_size=spatial_size,
+                                            stochastic_depth_prob=stochastic_depth_prob)
             if backbone == "mvit_rope":
                 self.use_rope = True
             in_features = 768

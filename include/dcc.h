@@ -118,6 +118,10 @@ int dcc_cast2d(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t ro
                int dst_dtype, void* stream);
 int dcc_axpby(void* out, float a, const void* x, float b, const void* y, int64_t n, int dtype, void* stream);
 int dcc_dgelu_mul(const void* dy, const void* pre, void* out, int64_t n, int dtype, void* stream);
+/* torchvision.ops.StochasticDepth(p, "row") of MultiscaleBlock (torchvision mvit.py via models/video_encoder.py:93):
+ * out = resid + x * scale[sample] with scale = bernoulli(1-p)/(1-p) per clip; resid may be null (backward). */
+int dcc_scale_rows(const void* x, const float* scale, const void* resid, void* out, int64_t samples,
+                   int64_t per_sample, int dtype, void* stream);
 int dcc_colsum(const void* x, int64_t ldx, float* out, int64_t M, int N, int dtype, void* stream);
 int dcc_broadcast_row(const float* src, void* dst, int64_t ld, int64_t rows, int C, int dtype, void* stream);
 /* mean over tokens (models/video_encoder.py:603) */

@@ -51,7 +51,8 @@ def test_video_encoder_vs_oracle(dtype, tol, gtol, pooling, N):
     T, S, B = 4, 64, 2
     orc = init_by_name(VideoEncoderOracle(T, (S, S), token_pooling_mode=pooling)).double()
     prod = VideoEncoder(backbone="mvit", num_frames=T, spatial_size=(S, S), pretrained=False, freeze_ratio=1.0,
-                        dropout=0.0, token_pooling_mode=pooling, attention_pool_dropout=0.0, compute_dtype=dtype)
+                        dropout=0.0, token_pooling_mode=pooling, attention_pool_dropout=0.0, compute_dtype=dtype,
+                        stochastic_depth_prob=0.0)
     prod.load_state_dict({k: v.float() for k, v in orc.state_dict().items()})
     prod = prod.cuda().float()
     x = _make_video(B, N, T, S)
@@ -74,7 +75,7 @@ def test_video_encoder_rope_tokens(dtype, tol):
     T, S, B, N = 4, 64, 1, 2
     orc = init_by_name(VideoEncoderOracle(T, (S, S), use_rope=True, aggregate_videos_tokens=False)).double()
     prod = VideoEncoder(num_frames=T, spatial_size=(S, S), pretrained=False, freeze_ratio=1.0, dropout=0.0, use_rope=True,
-                        aggregate_videos_tokens=False, per_video_pool=False, compute_dtype=dtype)
+                        aggregate_videos_tokens=False, per_video_pool=False, compute_dtype=dtype, stochastic_depth_prob=0.0)
     prod.load_state_dict({k: v.float() for k, v in orc.state_dict().items()})
     prod = prod.cuda()
     x = _make_video(B, N, T, S, seed=3)
@@ -109,3 +110,72 @@ def test_text_encoder_vs_oracle(dtype, tol, gtol):
     ref.backward(gg)
     out.backward(gg.to(out.dtype).cuda())
     _grad_check(prod, orc, {}, gtol)
+
+
+def test_video_encoder_c1_size_relpos_interpolation():
+    """BASELINE configs[0] geometry (4 frames, 112 x 112): the 7 -> 4 pooled grid is not what torchvision's floor
+    bookkeeping (7 // 2 = 3) sized the relative-position tables for, so they are linearly resampled
+    (torchvision mvit._interpolate) — forward and every parameter gradient against the oracle, fp32."""
+    from deepcoro_clip_amd.video_encoder import VideoEncoder
+    from oracle.model import VideoEncoderOracle, init_by_name
+
+    T, S, B = 4, 112, 2
+    orc = init_by_name(VideoEncoderOracle(T, (S, S))).double()
+    prod = VideoEncoder(num_frames=T, spatial_size=(S, S), pretrained=False, freeze_ratio=1.0, dropout=0.0,
+                        compute_dtype=torch.float32, stochastic_depth_prob=0.0)
+    prod.load_state_dict({k: v.float() for k, v in orc.state_dict().items()})
+    prod = prod.cuda()
+    assert any(w is not None for blk in prod.model.blocks for w in blk._idx(torch.device("cuda"))[2]), \
+        "this geometry must exercise the interpolation path"
+    x = _make_video(B, 0, T, S)
+    ref = orc(x.double())
+    out = prod(x.cuda())
+    assert _rel(out.cpu(), ref) < 2e-4, _rel(out.cpu(), ref)
+    g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1)).double()
+    ref.backward(g)
+    out.backward(g.float().cuda())
+    _grad_check(prod, orc, {"rel_pos": 8e-3}, 2e-3)
+
+
+def test_stochastic_depth_semantics():
+    """torchvision StochasticDepth(p, "row") on both residual branches: identity in eval mode (equals the oracle);
+    in train mode whole clips keep or drop a branch, survivors are scaled by 1/(1-p), gradients follow the mask."""
+    from deepcoro_clip_amd import functional as Fn
+    from deepcoro_clip_amd.video_encoder import VideoEncoder
+    from oracle.model import VideoEncoderOracle, init_by_name
+
+    # the fused kernel against its definition
+    gen = torch.Generator().manual_seed(3)
+    B, N, C = 6, 5, 64
+    resid = torch.randn(B * N, C, generator=gen).cuda().requires_grad_(True)
+    branch = torch.randn(B * N, C, generator=gen).cuda().requires_grad_(True)
+    scale = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25, 1.25], device="cuda")
+    out = Fn.StochasticDepthFn.apply(resid, branch, scale, B)
+    ref = resid.detach() + branch.detach() * scale.repeat_interleave(N)[:, None]
+    assert torch.allclose(out, ref, atol=1e-6)
+    out.sum().backward()
+    assert torch.equal(resid.grad, torch.ones_like(resid))
+    assert torch.allclose(branch.grad, scale.repeat_interleave(N)[:, None].expand(-1, C))
+    # model level
+    T, S = 4, 64
+    orc = init_by_name(VideoEncoderOracle(T, (S, S))).double()
+    prod = VideoEncoder(num_frames=T, spatial_size=(S, S), pretrained=False, freeze_ratio=1.0, dropout=0.0,
+                        compute_dtype=torch.float32)  # default stochastic_depth_prob = 0.2 like mvit_v2_s
+    prod.load_state_dict({k: v.float() for k, v in orc.state_dict().items()})
+    prod = prod.cuda()
+    assert [round(b.sd_prob, 4) for b in prod.model.blocks][::5] == [0.0, round(0.2 * 5 / 15, 4), round(0.2 * 10 / 15, 4), 0.2]
+    x = _make_video(8, 0, T, S)
+    ref = orc(x.double())
+    prod.eval()
+    assert _rel(prod(x.cuda()).cpu(), ref) < 2e-4
+    prod.train()
+    torch.manual_seed(0)
+    a = prod(x.cuda())
+    torch.manual_seed(0)
+    b = prod(x.cuda())
+    torch.manual_seed(1)
+    c = prod(x.cuda())
+    assert torch.equal(a, b) and not torch.equal(a, c), "masks come from torch's device generator"
+    assert _rel(a.cpu(), ref) > 1e-3, "training mode must actually drop branches"
+    a.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in prod.parameters() if p.grad is not None)

@@ -178,3 +178,30 @@ def test_gradient_accumulation_and_val_step():
         ref = contrastive_loss(vo(videos), to(ids, mask), lt).item()
     assert abs(vm["loss"] - ref) < 1e-4 * max(1.0, abs(ref))
     assert torch.equal(runner.video_encoder.model.blocks[0].attn.qkv.weight.detach().cpu(), before)
+
+
+def test_baseline_config0_geometry_steps():
+    """BASELINE configs[0]: single-video CLIP, 4 frames 112 x 112, 32-token text, batch 8, fp32 — three optimizer steps
+    against the CPU oracle (text tower shortened to 2 layers to keep the CPU side in seconds)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import make_tiny_setup
+    from oracle.losses import contrastive_loss
+
+    B = 8
+    runner, (vo, to), _ = make_tiny_setup(torch.float32, B=B, T=4, S=112, seq=32)
+    lt, opt = _oracle_trainer(vo, to, 0.07)
+    all_params = list(vo.parameters()) + list(to.parameters())
+    g = torch.Generator().manual_seed(7)
+    for step in range(3):
+        videos = torch.randn(B, 4, 112, 112, 3, generator=g)
+        ids = torch.randint(0, 512, (B, 32), generator=g)
+        mask = torch.ones(B, 32, dtype=torch.int64)
+        opt.zero_grad(set_to_none=True)
+        ref = contrastive_loss(vo(videos), to(ids, mask), lt)
+        ref.backward()
+        torch.nn.utils.clip_grad_norm_(all_params, 5.0)
+        opt.step()
+        m, emb = runner._train_step(videos=videos.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda())
+        assert abs(m["loss"] - ref.item()) < 1e-4 * max(1.0, abs(ref.item())), (step, m["loss"], ref.item())
+    assert emb["video_embeddings"].shape == (B, 512)
