@@ -109,14 +109,17 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
     // =============================================================================================== loader waves
     // per-lane source offsets (bytes from the tile origin at k = 0) of this wave's four DMA pieces per operand
     int voffA[PPL], voffB[PPL];
+    int kcA[PPL], kcB[PPL];  // k offset (elements) of this lane's chunk inside a K-step, k-contiguous operands only
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const int g = lw * PPL + j;
+      kcA[j] = kcB[j] = 0;
       if (A_KM) { const int R = g * 4 + (lane >> 4), c = (lane & 15) ^ swz_km128(R); voffA[j] = (R * (int)p.lda + c * 8) * 2; }
-      else { const int R = g * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7); voffA[j] = (R * (int)p.lda + c * 8) * 2; }
+      else { const int R = g * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7); voffA[j] = (R * (int)p.lda + c * 8) * 2; kcA[j] = c * 8; }
       if (B_KM) { const int R = g * 4 + (lane >> 4), c = (lane & 15) ^ swz_km128(R); voffB[j] = (R * (int)p.ldb + c * 8) * 2; }
-      else { const int R = g * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7); voffB[j] = (R * (int)p.ldb + c * 8) * 2; }
+      else { const int R = g * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7); voffB[j] = (R * (int)p.ldb + c * 8) * 2; kcB[j] = c * 8; }
     }
+    constexpr int OOB = 0x7fffff00;  // beyond any descriptor range (operands are < 2 GiB): reads as zero
     const bool bias_wave = lw < 2;  // two 256-byte pieces carry the tile's bias slice
     const int voffBias = ((lw & 1) * 64 + lane) * 4;
     const int kstrideA = A_KM ? BK * (int)p.lda * 2 : BK * 2;  // bytes per K-step
@@ -145,12 +148,18 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
       const int kb = L.ks0 + l_kt;
       // the K offset goes into the VGPR offset: the descriptor's range check does not see the scalar offset
       const int soA = kb * kstrideA, soB = kb * kstrideB;
+      // a k-contiguous operand's K tail (K % 64 != 0) would run into the next row: those chunks are sent out of range
+      const int k0 = kb * BK;
 #pragma unroll
-      for (int j = 0; j < PPL; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, st + (lw * PPL + j) * 1024), 16, voffA[j] + soA, 0, 0, 0);
+      for (int j = 0; j < PPL; ++j) {
+        const int vo = (!A_KM && k0 + kcA[j] >= p.K) ? OOB : voffA[j] + soA;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, st + (lw * PPL + j) * 1024), 16, vo, 0, 0, 0);
+      }
 #pragma unroll
-      for (int j = 0; j < PPL; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, st + TILE_B + (lw * PPL + j) * 1024), 16, voffB[j] + soB, 0, 0, 0);
+      for (int j = 0; j < PPL; ++j) {
+        const int vo = (!B_KM && k0 + kcB[j] >= p.K) ? OOB : voffB[j] + soB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, st + TILE_B + (lw * PPL + j) * 1024), 16, vo, 0, 0, 0);
+      }
       if (bias_wave)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LDS_PTR(void, st + 2 * TILE_B + (lw & 1) * 256), 4, voffBias, 0, 0, 0);
       ++loads_issued;
@@ -395,11 +404,11 @@ extern "C" int dcc_gemm_ring_profile(unsigned long long* out, int reset) {  // d
 #endif
 
 int dcc_gemm_ring_launch(const GemmParams& p, int a_km, int b_km, int out_dtype, hipStream_t st) {
-  // shapes the ring handles: 16-byte chunked operands/outputs, whole K-steps for k-contiguous operands (their tail
-  // cannot be zero-filled by a flat range check), 32-bit byte offsets
+  // shapes the ring handles: 16-byte chunked operands/outputs (K a multiple of 8 for k-contiguous operands), 32-bit
+  // byte offsets
   if ((p.lda % 8) || (p.ldb % 8) || (p.sA % 8) || (p.sB % 8) || (p.ldc % 8) || (p.N % 8) || (p.sC % 8)) return DCC_ERR_UNSUPPORTED;
   if ((a_km && (p.M % 8)) || (b_km && (p.N % 8))) return DCC_ERR_UNSUPPORTED;
-  if ((!a_km || !b_km) && (p.K % BK)) return DCC_ERR_UNSUPPORTED;
+  if ((!a_km || !b_km) && (p.K % 8)) return DCC_ERR_UNSUPPORTED;
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15) || ((uintptr_t)p.C & 15)) return DCC_ERR_UNSUPPORTED;
   if ((p.flags & GEMM_RESID) && ((p.ldr % 8) || ((uintptr_t)p.R & 15))) return DCC_ERR_UNSUPPORTED;
   if ((p.flags & (GEMM_SAVE_PRE | GEMM_DGELU)) && ((p.ldaux % 8) || ((uintptr_t)p.aux & 15))) return DCC_ERR_UNSUPPORTED;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const DccTensorDesc* __restri
   const int2 w = work[blockIdx.x];
   const DccTensorDesc t = tab[w.x];
   if (!t.g) return;
-  const float gs = grad_scale ? *grad_scale : 1.0f;
+  const float gs = (grad_scale && (t.flags & 2)) ? *grad_scale : 1.0f;  // flag 2: tensor is inside the clipped set
   const int64_t base = (int64_t)w.y * CHUNK;
   const float step_size = t.lr / t.bc1;
   const float bc2s = sqrtf(t.bc2);

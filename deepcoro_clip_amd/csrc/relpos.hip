@@ -26,56 +26,94 @@ struct RelGeom {
   int64_t sb, sn, sh;    // strides of the Qf-like operand (b, token, head)
 };
 
-template <typename T>
-__global__ void relpos_gather_kernel(T* __restrict__ Qf, const T* __restrict__ P, const int* __restrict__ idx_h,
-                                     const int* __restrict__ idx_w, const int* __restrict__ idx_t, RelGeom g,
-                                     float inv_scale) {
-  const int Nq = g.qt * g.qh * g.qw + g.has_cls;
-  const int64_t total = (int64_t)g.B * Nq * g.H * g.A;
-  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
-    const int j = id % g.A;
-    const int64_t row = id / g.A;  // (b, n, head) row of P
-    const int hd = row % g.H;
-    const int n = (row / g.H) % Nq;
-    const int b = row / ((int64_t)g.H * Nq);
-    float v = 0.0f;
-    if (!(g.has_cls && n == 0) && j < g.kh + g.kw + g.kt) {
-      const int i = n - g.has_cls;
-      const int w = i % g.qw, hh = (i / g.qw) % g.qh, t = i / (g.qw * g.qh);
-      int l;
-      if (j < g.kh) l = idx_h[hh * g.kh + j];
-      else if (j < g.kh + g.kw) l = g.Lh + idx_w[w * g.kw + (j - g.kh)];
-      else l = g.Lh + g.Lw + idx_t[t * g.kt + (j - g.kh - g.kw)];
-      v = to_f32(P[row * g.L + l]) * inv_scale;
-    }
-    Qf[b * g.sb + (int64_t)n * g.sn + hd * g.sh + g.D + j] = from_f32<T>(v);
+template <typename T> __device__ __forceinline__ void store8(T* dst, const float* v) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8*>(dst) = o;
+  } else {
+    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
   }
 }
 
+// One thread = 8 consecutive columns of one (b, token, head) row (16-byte bf16 / 2 x 16-byte fp32 stores); the row's
+// grid coordinates are decoded once per thread with 32-bit arithmetic.
 template <typename T>
-__global__ void relpos_scatter_kernel(const T* __restrict__ dQf, T* __restrict__ dP, const int* __restrict__ inv_h,
-                                      const int* __restrict__ inv_w, const int* __restrict__ inv_t, RelGeom g,
-                                      float inv_scale) {
+__global__ __launch_bounds__(256) void relpos_gather_kernel(T* __restrict__ Qf, const T* __restrict__ P,
+                                                            const int* __restrict__ idx_h, const int* __restrict__ idx_w,
+                                                            const int* __restrict__ idx_t, RelGeom g, float inv_scale) {
   const int Nq = g.qt * g.qh * g.qw + g.has_cls;
-  const int64_t total = (int64_t)g.B * Nq * g.H * g.L;
-  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
-    const int l = id % g.L;
-    const int64_t row = id / g.L;
-    const int hd = row % g.H;
-    const int n = (row / g.H) % Nq;
-    const int b = row / ((int64_t)g.H * Nq);
-    float v = 0.0f;
-    if (!(g.has_cls && n == 0) && l < g.Lh + g.Lw + g.Lt) {
-      const int i = n - g.has_cls;
-      const int w = i % g.qw, hh = (i / g.qw) % g.qh, t = i / (g.qw * g.qh);
-      int j;
-      if (l < g.Lh) { j = inv_h[hh * g.Lh + l]; }
-      else if (l < g.Lh + g.Lw) { j = inv_w[w * g.Lw + (l - g.Lh)]; if (j >= 0) j += g.kh; }
-      else { j = inv_t[t * g.Lt + (l - g.Lh - g.Lw)]; if (j >= 0) j += g.kh + g.kw; }
-      if (j >= 0) v = to_f32(dQf[b * g.sb + (int64_t)n * g.sn + hd * g.sh + g.D + j]) * inv_scale;
+  const int cpr = g.A / 8;  // A is a multiple of 32
+  const unsigned total = (unsigned)g.B * Nq * g.H * cpr;
+  const unsigned id = blockIdx.x * 256u + threadIdx.x;
+  if (id >= total) return;
+  const unsigned row = id / cpr;  // (b, n, head) row of P
+  const int j0 = (id - row * cpr) * 8;
+  const unsigned bn = row / g.H;
+  const int hd = row - bn * g.H;
+  const unsigned b = bn / Nq;
+  const int n = bn - b * Nq;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+  if (!(g.has_cls && n == 0)) {
+    const int i = n - g.has_cls;
+    const int t = i / (g.qw * g.qh), r = i - t * (g.qw * g.qh);
+    const int hh = r / g.qw, w = r - hh * g.qw;
+    const T* prow = P + (int64_t)row * g.L;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = j0 + e;
+      if (j < g.kh + g.kw + g.kt) {
+        int l;
+        if (j < g.kh) l = idx_h[hh * g.kh + j];
+        else if (j < g.kh + g.kw) l = g.Lh + idx_w[w * g.kw + (j - g.kh)];
+        else l = g.Lh + g.Lw + idx_t[t * g.kt + (j - g.kh - g.kw)];
+        v[e] = to_f32(prow[l]) * inv_scale;
+      }
     }
-    dP[id] = from_f32<T>(v);
   }
+  store8<T>(Qf + b * g.sb + (int64_t)n * g.sn + hd * g.sh + g.D + j0, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_scatter_kernel(const T* __restrict__ dQf, T* __restrict__ dP,
+                                                             const int* __restrict__ inv_h, const int* __restrict__ inv_w,
+                                                             const int* __restrict__ inv_t, RelGeom g, float inv_scale) {
+  const int Nq = g.qt * g.qh * g.qw + g.has_cls;
+  const int cpr = g.L / 8;  // L is a multiple of 32
+  const unsigned total = (unsigned)g.B * Nq * g.H * cpr;
+  const unsigned id = blockIdx.x * 256u + threadIdx.x;
+  if (id >= total) return;
+  const unsigned row = id / cpr;
+  const int l0 = (id - row * cpr) * 8;
+  const unsigned bn = row / g.H;
+  const int hd = row - bn * g.H;
+  const unsigned b = bn / Nq;
+  const int n = bn - b * Nq;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+  if (!(g.has_cls && n == 0)) {
+    const int i = n - g.has_cls;
+    const int t = i / (g.qw * g.qh), r = i - t * (g.qw * g.qh);
+    const int hh = r / g.qw, w = r - hh * g.qw;
+    const T* src = dQf + b * g.sb + (int64_t)n * g.sn + hd * g.sh + g.D;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int l = l0 + e;
+      if (l < g.Lh + g.Lw + g.Lt) {
+        int j;
+        if (l < g.Lh) { j = inv_h[hh * g.Lh + l]; }
+        else if (l < g.Lh + g.Lw) { j = inv_w[w * g.Lw + (l - g.Lh)]; if (j >= 0) j += g.kh; }
+        else { j = inv_t[t * g.Lt + (l - g.Lh - g.Lw)]; if (j >= 0) j += g.kh + g.kw; }
+        if (j >= 0) v[e] = to_f32(src[j]) * inv_scale;
+      }
+    }
+  }
+  store8<T>(dP + (int64_t)row * g.L + l0, v);
 }
 
 // one-hot key augmentation, one thread per (b, n, head, j)
@@ -123,10 +161,12 @@ extern "C" int dcc_relpos_gather(void* Qf, const void* P, const int* idx_h, cons
   if (!Qf || !P || !idx_h || !idx_w || !idx_t || !dims || !strides) return DCC_ERR_ARG;
   RelGeom g = mk(dims, strides);
   if (g.A < g.kh + g.kw + g.kt || g.L < g.Lh + g.Lw + g.Lt) return DCC_ERR_ARG;
-  const int64_t total = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H * g.A;
+  if ((g.A % 8) || (g.L % 8)) return DCC_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H * (g.A / 8);
+  if (total >= (1LL << 31)) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DCC_BF16) hipLaunchKernelGGL((relpos_gather_kernel<bf16_t>), dim3(gsb(total)), dim3(256), 0, st, (bf16_t*)Qf, (const bf16_t*)P, idx_h, idx_w, idx_t, g, 1.0f / scale);
-  else if (dtype == DCC_F32) hipLaunchKernelGGL((relpos_gather_kernel<float>), dim3(gsb(total)), dim3(256), 0, st, (float*)Qf, (const float*)P, idx_h, idx_w, idx_t, g, 1.0f / scale);
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((relpos_gather_kernel<bf16_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (bf16_t*)Qf, (const bf16_t*)P, idx_h, idx_w, idx_t, g, 1.0f / scale);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((relpos_gather_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (float*)Qf, (const float*)P, idx_h, idx_w, idx_t, g, 1.0f / scale);
   else return DCC_ERR_UNSUPPORTED;
   return dcc_check_launch();
 }
@@ -136,10 +176,12 @@ extern "C" int dcc_relpos_scatter(const void* dQf, void* dP, const int* inv_h, c
                                   const int* dims, const int64_t* strides, float scale, int dtype, void* stream) {
   if (!dQf || !dP || !inv_h || !inv_w || !inv_t || !dims || !strides) return DCC_ERR_ARG;
   RelGeom g = mk(dims, strides);
-  const int64_t total = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H * g.L;
+  if ((g.A % 8) || (g.L % 8)) return DCC_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H * (g.L / 8);
+  if (total >= (1LL << 31)) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DCC_BF16) hipLaunchKernelGGL((relpos_scatter_kernel<bf16_t>), dim3(gsb(total)), dim3(256), 0, st, (const bf16_t*)dQf, (bf16_t*)dP, inv_h, inv_w, inv_t, g, 1.0f / scale);
-  else if (dtype == DCC_F32) hipLaunchKernelGGL((relpos_scatter_kernel<float>), dim3(gsb(total)), dim3(256), 0, st, (const float*)dQf, (float*)dP, inv_h, inv_w, inv_t, g, 1.0f / scale);
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((relpos_scatter_kernel<bf16_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)dQf, (bf16_t*)dP, inv_h, inv_w, inv_t, g, 1.0f / scale);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((relpos_scatter_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)dQf, (float*)dP, inv_h, inv_w, inv_t, g, 1.0f / scale);
   else return DCC_ERR_UNSUPPORTED;
   return dcc_check_launch();
 }

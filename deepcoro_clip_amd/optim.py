@@ -85,14 +85,23 @@ class GradClipper:
             d[i]["n"] = p.numel()
         return d
 
-    def clip_(self, max_norm: float) -> torch.Tensor:
+    def clip_(self, max_norm: float, scale: bool = True) -> torch.Tensor:
+        """scale=False only computes `self.coef` (device scalar): HipAdamW.step(grad_scale=coef, scaled=params) then
+        applies it while it reads the gradients anyway, saving one read+write pass over all of them."""
         t = self.table
         t.upload(self._desc())
         self.sumsq.zero_()
         L.call("dcc_grad_sumsq", L.ptr(t.dev), L.ptr(t.work), t.nblocks, L.ptr(self.sumsq), L.stream())
         L.call("dcc_clip_coef", L.ptr(self.sumsq), float(max_norm), L.ptr(self.coef), L.ptr(self.norm), L.stream())
-        L.call("dcc_scale_grads", L.ptr(t.dev), L.ptr(t.work), t.nblocks, L.ptr(self.coef), L.stream())
+        if scale:
+            L.call("dcc_scale_grads", L.ptr(t.dev), L.ptr(t.work), t.nblocks, L.ptr(self.coef), L.stream())
         return self.norm
+
+    def scale_with(self, coef: torch.Tensor) -> None:
+        """Scale this clipper's gradients in place by a coefficient computed elsewhere (device scalar)."""
+        t = self.table
+        t.upload(self._desc())
+        L.call("dcc_scale_grads", L.ptr(t.dev), L.ptr(t.work), t.nblocks, L.ptr(coef), L.stream())
 
 
 class HipAdamW(torch.optim.Optimizer):
@@ -130,11 +139,14 @@ class HipAdamW(torch.optim.Optimizer):
         self._table = _TensorTable(self._plist)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: torch.Tensor | None = None):
+    def step(self, closure=None, grad_scale: torch.Tensor | None = None, scaled: set | None = None):
+        """grad_scale: device scalar multiplied into the gradients of the parameters whose id() is in `scaled`
+        (all parameters when `scaled` is None) — the clip coefficient of GradClipper.clip_(scale=False)."""
         loss = closure() if closure is not None else None
         if self._table is None or len(self._plist) != sum(len(g["params"]) for g in self.param_groups):
             self._build()
         d = np.zeros(len(self._plist), dtype=_DESC)
+        refreshed: list = []
         i = 0
         for g in self.param_groups:
             b1, b2 = g["betas"]
@@ -148,9 +160,15 @@ class HipAdamW(torch.optim.Optimizer):
                         st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["step"] = st["step"] + 1 if torch.is_tensor(st["step"]) else st["step"] + 1
                     k = float(st["step"])
-                    d[i] = (p.data_ptr(), gp, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), 0, p.numel(),
-                            float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], 1.0 - b1 ** k, 1.0 - b2 ** k,
-                            1 if g.get("adamw", True) else 0)
+                    # a whole-parameter bf16 shadow (functional.wcast) is refreshed by the update kernel itself
+                    shadow, skey = 0, (0, tuple(p.shape), tuple(p.stride()), torch.bfloat16)
+                    cache = p.__dict__.get("_dcc_shadows")
+                    if cache is not None and skey in cache and p.is_contiguous():
+                        shadow = cache[skey][1].data_ptr()
+                        refreshed.append((p, skey))
+                    flags = (1 if g.get("adamw", True) else 0) | (2 if (scaled is None or id(p) in scaled) else 0)
+                    d[i] = (p.data_ptr(), gp, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), shadow, p.numel(),
+                            float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], 1.0 - b1 ** k, 1.0 - b2 ** k, flags)
                     if not p.is_contiguous():
                         raise L.DccError("HIP optimizer expects contiguous parameters")
                 else:
@@ -160,4 +178,7 @@ class HipAdamW(torch.optim.Optimizer):
         t.upload(d)
         L.call("dcc_adam_step", L.ptr(t.dev), L.ptr(t.work), t.nblocks, L.ptr(grad_scale), L.stream())
         Fn.invalidate_weight_cache()  # parameters changed behind autograd's version counters
+        for p, skey in refreshed:    # ... except the shadows the kernel just rewrote
+            cache = p.__dict__["_dcc_shadows"]
+            cache[skey] = ((p._version, Fn._WEPOCH, p.data_ptr()), cache[skey][1])
         return loss

@@ -71,6 +71,7 @@ class VideoContrastiveLearningRunner:
         self.weighted_siglip_loss = WeightedSigLIPLoss() if self.use_weighted_siglip else None
         self.siglip_abnormal_margin = float(_cfg(config, "siglip_abnormal_margin", 0.0))
         self._clipper: GradClipper | None = None
+        self._orphan_clipper: GradClipper | None = None
         self._accum_grad: torch.Tensor | None = None
 
     # ------------------------------------------------------------------------------------------ helpers
@@ -218,10 +219,22 @@ class VideoContrastiveLearningRunner:
         if boundary:
             for w in self._ddp_wrappers():
                 w.finish()  # join the overlapped bucket all-reduces (RCCL)
+            fused_clip = None
             if max_norm:
                 if self._clipper is None:
                     self._clipper = GradClipper(self._all_encoder_params())
-                self._clipper.clip_(float(max_norm))
+                    self._clipped_ids = {id(p) for p in self._clipper.params}
+                    # clipped parameters outside every optimizer group (the reference's video `proj`):
+                    # nobody zeroes their .grad, so it keeps accumulating and keeps being rescaled in place — that
+                    # history feeds the norm of every later step and must be reproduced
+                    in_opt = {id(p) for g in self.optimizer.param_groups for p in g["params"]}
+                    orphans = [p for p in self._clipper.params if id(p) not in in_opt]
+                    self._orphan_clipper = GradClipper(orphans) if orphans else None
+                fuse = isinstance(self.optimizer, HipAdamW)  # the update kernel applies the coefficient on the fly
+                self._clipper.clip_(float(max_norm), scale=not fuse)
+                fused_clip = self._clipper.coef if fuse else None
+                if fuse and self._orphan_clipper is not None:
+                    self._orphan_clipper.scale_with(self._clipper.coef)
             if isinstance(self.log_temp, torch.nn.Parameter) and self.log_temp.grad is not None and dist.is_available() \
                     and dist.is_initialized() and dist.get_world_size() > 1:
                 if dist.get_backend() == "nccl":
@@ -229,7 +242,10 @@ class VideoContrastiveLearningRunner:
                 else:
                     dist.all_reduce(self.log_temp.grad, op=dist.ReduceOp.SUM)
                     self.log_temp.grad.div_(dist.get_world_size())
-            self.optimizer.step()
+            if fused_clip is not None:
+                self.optimizer.step(grad_scale=fused_clip, scaled=self._clipped_ids)
+            else:
+                self.optimizer.step()
             if not isinstance(self.optimizer, HipAdamW):
                 Fn.invalidate_weight_cache()
             if self.lr_scheduler and self.scheduler_per_iteration and self.step > 0:

@@ -119,7 +119,8 @@ def _ring_case(M, N, K, a_km, b_km, out_dtype=torch.float32, splitk=1, seed=0, *
 
 
 @pytest.mark.parametrize("a_km,b_km", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(3000, 1536, 384), (2049, 1160, 192), (25089, 96, 128), (1569, 3072, 64), (4096, 512, 1024)])
+@pytest.mark.parametrize("M,N,K", [(3000, 1536, 384), (2049, 1160, 192), (25089, 96, 128), (1569, 3072, 64), (4096, 512, 1024),
+                                   (25089, 288, 96), (6273, 576, 72), (3000, 1536, 200)])
 def test_ring_layouts_exact(a_km, b_km, M, N, K):
     if (a_km and M % 8) or (b_km and N % 8):
         pytest.skip("k-major operands need 16-byte row chunks")
