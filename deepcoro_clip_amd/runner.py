@@ -72,6 +72,7 @@ class VideoContrastiveLearningRunner:
         self.siglip_abnormal_margin = float(_cfg(config, "siglip_abnormal_margin", 0.0))
         self._clipper: GradClipper | None = None
         self._orphan_clipper: GradClipper | None = None
+        self._text_stream: torch.cuda.Stream | None = None
         self._accum_grad: torch.Tensor | None = None
 
     # ------------------------------------------------------------------------------------------ helpers
@@ -116,8 +117,25 @@ class VideoContrastiveLearningRunner:
         return step_inputs, batch.get("paths", [])
 
     def _encode(self, videos, input_ids, attention_mask):
-        video_emb = self.video_encoder(videos)
-        text_emb = self.text_encoder(input_ids, attention_mask) if (input_ids is not None and attention_mask is not None) else None
+        # The towers are independent until the loss: the text tower (B x S = a few hundred tokens, ~200 small
+        # latency-bound kernels) runs on a side HIP stream underneath the video tower's large kernels, forward and —
+        # because autograd replays each node on its forward stream — backward too.
+        text_emb = None
+        if input_ids is not None and attention_mask is not None:
+            if self._text_stream is None:
+                self._text_stream = torch.cuda.Stream(device=videos.device)
+            main = torch.cuda.current_stream()
+            self._text_stream.wait_stream(main)
+            # video first: the host runs far ahead of the GPU, so the text kernels still start at once on their own
+            # stream, and autograd (reverse creation order) then enqueues the text BACKWARD first, which lets it
+            # overlap the video backward as well
+            video_emb = self.video_encoder(videos)
+            with torch.cuda.stream(self._text_stream):
+                text_emb = self.text_encoder(input_ids, attention_mask)
+            main.wait_stream(self._text_stream)
+            text_emb.record_stream(main)
+        else:
+            video_emb = self.video_encoder(videos)
         # torch.nan_to_num(emb, nan=0, posinf=1e4, neginf=-1e4): applied in place on the embedding storage (finite
         # after this, so the reference's isfinite().all() zeroing branch is unreachable and needs no host sync)
         K.nan_to_num_(video_emb.detach(), 0.0, 1e4, -1e4)
