@@ -579,6 +579,64 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_strided_kernel(const TD* __r
   store_cv<T, CV>(dx + b * g.sxb + (int64_t)(g.has_cls + (t * g.Hs + hh) * g.Ws + ww) * g.sxn + hd * g.sxh + c * CV, acc);
 }
 
+// skip-path max-pool data gradient: MaxPool3d k(1,3,3) s(1,2,2) p(0,1,1) with the argmax recorded by the forward
+// (tap = kh * 3 + kw).  One thread per input position chunk; the <= 2 x 2 windows that contain the position are
+// enumerated exactly (the generic kernel tests all 9 taps with 64-bit index arithmetic).
+template <typename T, typename TD>
+__global__ __launch_bounds__(256) void maxpool_s2_bwd_kernel(const TD* __restrict__ dy, T* __restrict__ dx,
+                                                             const uint8_t* __restrict__ argmax, RunGeom r) {
+  constexpr int CV = Vec16<T>::N;
+  const PoolGeom& g = r.g;
+  const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
+  const int c = threadIdx.x - rs * r.cpr;
+  if ((int)rs >= r.slots) return;
+  const unsigned id = blockIdx.x * r.slots + rs;
+  const int npos = g.B * g.H * g.T * g.Hs * g.Ws;
+  float acc[CV];
+#pragma unroll
+  for (int e = 0; e < CV; ++e) acc[e] = 0.0f;
+  if ((int)id >= npos) {
+    const int i = id - npos;
+    if (g.has_cls && i < g.B * g.H) {
+      const int b = i / g.H, hd = i - b * g.H;
+      load_cv<TD, CV>(dy + b * g.syb + hd * g.syh + c * CV, acc);
+      store_cv<T, CV>(dx + b * g.sxb + hd * g.sxh + c * CV, acc);
+    }
+    return;
+  }
+  const unsigned t1 = fdiv(id, r.d_Ws);
+  const int ww = id - t1 * g.Ws;
+  const unsigned t2 = fdiv(t1, r.d_Hs);
+  const int hh = t1 - t2 * g.Hs;
+  const unsigned t3 = fdiv(t2, r.d_T);
+  const int t = t2 - t3 * g.T;
+  const unsigned t4 = fdiv(t3, r.d_H);
+  const int hd = t3 - t4 * g.H, b = t4;
+  const int No = g.To * g.Ho * g.Wo + g.has_cls;
+  // windows o with 2 o - 1 + k == coordinate: even -> (k 1, o x/2); odd -> (k 0, o (x+1)/2), (k 2, o (x-1)/2)
+  int khs[2], hos[2], kws[2], wos[2];
+  const int nh = (hh & 1) ? 2 : 1, nw = (ww & 1) ? 2 : 1;
+  if (hh & 1) { khs[0] = 0; hos[0] = (hh + 1) >> 1; khs[1] = 2; hos[1] = (hh - 1) >> 1; } else { khs[0] = 1; hos[0] = hh >> 1; khs[1] = 1; hos[1] = hh >> 1; }
+  if (ww & 1) { kws[0] = 0; wos[0] = (ww + 1) >> 1; kws[1] = 2; wos[1] = (ww - 1) >> 1; } else { kws[0] = 1; wos[0] = ww >> 1; kws[1] = 1; wos[1] = ww >> 1; }
+  for (int a = 0; a < nh; ++a) {
+    if (hos[a] >= g.Ho) continue;
+    for (int bb = 0; bb < nw; ++bb) {
+      if (wos[bb] >= g.Wo) continue;
+      const int no = g.has_cls + (t * g.Ho + hos[a]) * g.Wo + wos[bb];
+      const int tap = khs[a] * 3 + kws[bb];
+      float f[CV];
+      load_cv<TD, CV>(dy + b * g.syb + (int64_t)no * g.syn + hd * g.syh + c * CV, f);
+      const uint8_t* am = argmax + ((((int64_t)b * No + no) * g.H + hd) * g.C + c * CV);
+      uint8_t a8[CV];
+      if constexpr (CV == 8) { const u32x2 v = *reinterpret_cast<const u32x2*>(am); __builtin_memcpy(a8, &v, 8); }
+      else { const uint32_t v = *reinterpret_cast<const uint32_t*>(am); __builtin_memcpy(a8, &v, 4); }
+#pragma unroll
+      for (int e = 0; e < CV; ++e) acc[e] += (a8[e] == tap) ? f[e] : 0.0f;
+    }
+  }
+  store_cv<T, CV>(dx + b * g.sxb + (int64_t)(g.has_cls + (t * g.Hs + hh) * g.Ws + ww) * g.sxn + hd * g.sxh + c * CV, acc);
+}
+
 // weight gradient: thread = (chunk, temporal tap kt, run slot); block partial -> ws[blockIdx.x][27][C]
 template <typename T, typename TD, int S, int WT>
 __global__ __launch_bounds__(256) void dw3_wgrad_kernel(const TD* __restrict__ dy, const T* __restrict__ x,
@@ -817,6 +875,17 @@ extern "C" int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const
   int rc = geom_ok(g, vec);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (mode == 1 && g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 2 && g.sw == 2 && g.pt == 0 && g.ph == 1 &&
+      g.pw == 1 && (g.C / vec) <= 64 && (int64_t)g.B * g.H * g.T * g.Hs * g.Ws < (1 << 25)) {
+    const RunGeom r = make_run_geom(g, vec, 4);
+    const int items = g.B * g.H * g.T * g.Hs * g.Ws + (g.has_cls ? g.B * g.H : 0);
+    const dim3 grid((items + r.slots - 1) / r.slots);
+    if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) hipLaunchKernelGGL((maxpool_s2_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, argmax, r);
+    else if (dtype == DCC_BF16 && grad_dtype == DCC_F32) hipLaunchKernelGGL((maxpool_s2_bwd_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const float*)dy, (bf16_t*)dx, argmax, r);
+    else if (dtype == DCC_F32 && grad_dtype == DCC_F32) hipLaunchKernelGGL((maxpool_s2_bwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)dy, (float*)dx, argmax, r);
+    else return DCC_ERR_UNSUPPORTED;
+    return dcc_check_launch();
+  }
   if (mode == 0) {
     const int S = dw3_stride(g, vec);
     if (S == 1) {

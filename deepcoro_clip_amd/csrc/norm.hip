@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
                                                      int64_t ldx, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      TD* __restrict__ dx, int64_t lddx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int64_t rows, int C) {
+                                                     float* __restrict__ dbeta, int64_t rows, int C,
+                                                     const TD* __restrict__ dres) {
   constexpr int VEC = Vec16<T>::N;
   constexpr int RPW = 64 / LPR;
   using V = vec16_t<T>;
@@ -169,6 +170,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
           float o[VEC];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) o[e] = rs * (g[it][e] - s1 - xh[it][e] * s2);
+          if (dres) {  // gradient arriving through the other use of x (residual / skip path): summed here, not by autograd
+            float rr[VEC];
+            load_vecf<TD, VEC>(dres + row * lddx + c * VEC, rr);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] += rr[e];
+          }
           store_vecf<TD, VEC>(dx + row * lddx + c * VEC, o);
         }
       }
@@ -239,11 +246,12 @@ int ln_fwd_t(const void* x, int64_t ldx, void* y, int64_t ldy, const float* g, c
 
 template <typename T, typename TD>
 int ln_bwd_t(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean, const float* rstd,
-             const float* g, void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t st) {
+             const float* g, void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int C, const void* dres,
+             hipStream_t st) {
   int lpr, iters;
   if (pick(C / Vec16<T>::N, lpr, iters)) return DCC_ERR_UNSUPPORTED;
-  const TD* dyp = (const TD*)dy; const T* xp = (const T*)x; TD* dxp = (TD*)dx;
-#define LN_B(LP, IT) hipLaunchKernelGGL((ln_bwd_kernel<T, TD, LP, IT>), dim3(grid_for(rows, 64 / LP) > 512 ? 512 : grid_for(rows, 64 / LP)), dim3(256), 2 * C * sizeof(float), st, dyp, lddy, xp, ldx, mean, rstd, g, dxp, lddx, dgamma, dbeta, rows, C)
+  const TD* dyp = (const TD*)dy; const T* xp = (const T*)x; TD* dxp = (TD*)dx; const TD* drp = (const TD*)dres;
+#define LN_B(LP, IT) hipLaunchKernelGGL((ln_bwd_kernel<T, TD, LP, IT>), dim3(grid_for(rows, 64 / LP) > 512 ? 512 : grid_for(rows, 64 / LP)), dim3(256), 2 * C * sizeof(float), st, dyp, lddy, xp, ldx, mean, rstd, g, dxp, lddx, dgamma, dbeta, rows, C, drp)
   if (lpr == 16) LN_B(16, 1);
   else if (lpr == 32) LN_B(32, 1);
   else if (iters == 1) LN_B(64, 1);
@@ -271,18 +279,19 @@ extern "C" int dcc_layernorm_fwd(const void* x, int64_t ldx, void* y, int64_t ld
 // dgamma / dbeta are ACCUMULATED into (fp32, caller zeroes or owns the running gradient).
 extern "C" int dcc_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean,
                                  const float* rstd, const float* gamma, void* dx, int64_t lddx, float* dgamma,
-                                 float* dbeta, int64_t rows, int C, int dtype, int grad_dtype, void* stream) {
+                                 float* dbeta, const void* dres, int64_t rows, int C, int dtype, int grad_dtype,
+                                 void* stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !dx || rows <= 0 || C <= 0) return DCC_ERR_ARG;
   const int vec = dtype == DCC_BF16 ? 8 : 4;
   if ((C % vec) || (ldx % vec) || ((uintptr_t)x & 15)) return DCC_ERR_UNSUPPORTED;
   const int gvec = grad_dtype == DCC_BF16 ? 8 : 4;
-  if ((lddy % gvec) || (lddx % gvec) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return DCC_ERR_UNSUPPORTED;
+  if ((lddy % gvec) || (lddx % gvec) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) || ((uintptr_t)dres & 15)) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DCC_BF16 && grad_dtype == DCC_BF16)
-    return ln_bwd_t<bf16_t, bf16_t>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, st);
+    return ln_bwd_t<bf16_t, bf16_t>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, dres, st);
   if (dtype == DCC_BF16 && grad_dtype == DCC_F32)
-    return ln_bwd_t<bf16_t, float>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, st);
+    return ln_bwd_t<bf16_t, float>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, dres, st);
   if (dtype == DCC_F32 && grad_dtype == DCC_F32)
-    return ln_bwd_t<float, float>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, st);
+    return ln_bwd_t<float, float>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, dres, st);
   return DCC_ERR_UNSUPPORTED;
 }

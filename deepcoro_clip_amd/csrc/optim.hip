@@ -20,23 +20,35 @@ namespace {
 
 constexpr int CHUNK = 4096;  // elements per work item; DCC_OPT_CHUNK in include/dcc.h
 
+// grid-stride over the (tensor, chunk) work list: a block folds many chunks in registers and ends with ONE fp64 atomic
+// (one atomic per 16-KiB chunk on a single address was the whole cost of the first version)
 __global__ __launch_bounds__(256) void sumsq_kernel(const DccTensorDesc* __restrict__ tab, const int2* __restrict__ work,
-                                                    double* __restrict__ out) {
-  const int2 w = work[blockIdx.x];
-  const DccTensorDesc t = tab[w.x];
-  const int64_t base = (int64_t)w.y * CHUNK;
+                                                    int nwork, double* __restrict__ out) {
   float acc = 0.0f;
-  if (t.g) {
-    for (int i = threadIdx.x; i < CHUNK; i += 256) {
-      const int64_t j = base + i;
-      if (j < t.n) { const float g = t.g[j]; acc += g * g; }
+  for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const int2 w = work[wi];
+    const DccTensorDesc t = tab[w.x];
+    if (!t.g) continue;
+    const int64_t base = (int64_t)w.y * CHUNK;
+    if (base + CHUNK <= t.n && (((uintptr_t)t.g) & 15) == 0) {
+      const f32x4* g4 = reinterpret_cast<const f32x4*>(t.g + base);
+#pragma unroll
+      for (int i = 0; i < CHUNK / 4 / 256; ++i) {
+        const f32x4 g = g4[threadIdx.x + 256 * i];
+        acc += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
+      }
+    } else {
+      for (int i = threadIdx.x; i < CHUNK; i += 256) {
+        const int64_t j = base + i;
+        if (j < t.n) { const float g = t.g[j]; acc += g * g; }
+      }
     }
   }
   acc = wave_sum(acc);
   __shared__ float part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (double)(part[0] + part[1] + part[2] + part[3]));
+  if (threadIdx.x == 0) atomicAdd(out, (double)part[0] + (double)part[1] + (double)part[2] + (double)part[3]);
 }
 
 // coef = min(1, max_norm / (norm + 1e-6)); norm_out = norm   (torch.nn.utils.clip_grad_norm_ semantics)
@@ -94,8 +106,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const DccTensorDesc* __restri
 // tab: device array of DccTensorDesc; work: device int2[nblocks] = (tensor index, chunk index)
 extern "C" int dcc_grad_sumsq(const void* tab, const void* work, int nblocks, double* out, void* stream) {
   if (!tab || !work || !out || nblocks <= 0) return DCC_ERR_ARG;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const DccTensorDesc*)tab,
-                     (const int2*)work, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks < 2048 ? nblocks : 2048), dim3(256), 0, (hipStream_t)stream,
+                     (const DccTensorDesc*)tab, (const int2*)work, nblocks, out);
   return dcc_check_launch();
 }
 extern "C" int dcc_clip_coef(const double* sumsq, float max_norm, float* coef, float* norm_out, void* stream) {

@@ -225,6 +225,36 @@ def layernorm(x, gamma, beta, eps: float):
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
+class LayerNormSkipFn(torch.autograd.Function):
+    """(LayerNorm(x), x): the pre-norm transformer pattern where x also feeds the residual branch.  Returning x through
+    the node lets backward receive BOTH gradients and add them inside the LayerNorm-backward kernel, instead of
+    autograd launching a separate elementwise add (one extra read+write pass per residual) per block."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        y, mean, rstd = K.layernorm_fwd(x2, gamma.detach(), beta.detach(), eps)
+        ctx.save_for_backward(x2, mean, rstd, gamma.detach())
+        ctx.xshape = x.shape
+        return y.reshape(x.shape), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x2, mean, rstd, gamma = ctx.saved_tensors
+        C = x2.shape[1]
+        dy2 = _as_dtype(_c(dy).reshape(-1, C), x2.dtype)
+        dr2 = _as_dtype(_c(dskip).reshape(-1, C), x2.dtype) if dskip is not None else None
+        dgb = zeros_f32((2, C), x2.device)
+        dx = K.layernorm_bwd(dy2, x2, mean, rstd, gamma, dgb[0], dgb[1], dres=dr2)
+        return dx.reshape(ctx.xshape), dgb[0], dgb[1], None
+
+
+def layernorm_skip(x, gamma, beta, eps: float):
+    """-> (LayerNorm(x), x') with x' an alias of x to be used by the residual / skip branch."""
+    return LayerNormSkipFn.apply(x, gamma, beta, eps)
+
+
 # ---------------------------------------------------------------------------------- attention
 class AttentionFn(torch.autograd.Function):
     """softmax(scale q k^T + kbias) v on [B, N, H, D] views (BERT self-attention, nn.MultiheadAttention core)."""

@@ -245,17 +245,20 @@ def layernorm_fwd(x2d: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ep
     return out, mean, rstd
 
 
-def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dgamma, dbeta, dx: torch.Tensor | None = None):
-    """dgamma/dbeta (fp32) are accumulated into. dy2d may be fp32 while x is bf16; dx takes dy's dtype."""
-    L.require_cuda(dy2d, x2d, dx)
+def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dgamma, dbeta, dx: torch.Tensor | None = None,
+                  dres: torch.Tensor | None = None):
+    """dgamma/dbeta (fp32) are accumulated into. dy2d may be fp32 while x is bf16; dx takes dy's dtype.
+    dres: gradient of x's other use (residual branch), added into dx in the same pass."""
+    L.require_cuda(dy2d, x2d, dx, dres)
     rows, C = x2d.shape
     assert dy2d.shape == (rows, C) and dy2d.stride(1) == 1 and x2d.stride(1) == 1
     if dx is None:
         dx = torch.empty((rows, C), device=x2d.device, dtype=dy2d.dtype)
     assert dx.dtype == dy2d.dtype and dx.stride(1) == 1
+    assert dres is None or (dres.shape == (rows, C) and dres.dtype == dx.dtype and dres.stride() == dx.stride())
     L.call("dcc_layernorm_bwd", L.ptr(dy2d), dy2d.stride(0), L.ptr(x2d), x2d.stride(0), L.ptr(mean), L.ptr(rstd),
-           L.ptr(gamma), L.ptr(dx), dx.stride(0), L.ptr(dgamma), L.ptr(dbeta), rows, C, L.dt(x2d), L.dt(dy2d),
-           L.stream())
+           L.ptr(gamma), L.ptr(dx), dx.stride(0), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), rows, C, L.dt(x2d),
+           L.dt(dy2d), L.stream())
     return dx
 
 

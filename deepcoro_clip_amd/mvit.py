@@ -119,7 +119,10 @@ class _Block(nn.Module):
         p, a = self.p, self.attn
         hd = a.head_dim
         N = x.shape[0] // Bp
-        xn1 = Fn.layernorm(x, self.norm1.weight, self.norm1.bias, self.eps)
+        if self.project is None:  # x feeds norm1 and, unchanged, the skip branch: their gradients meet in one kernel
+            xn1, x = Fn.layernorm_skip(x, self.norm1.weight, self.norm1.bias, self.eps)
+        else:
+            xn1 = Fn.layernorm(x, self.norm1.weight, self.norm1.bias, self.eps)
         qkv = Fn.linear(xn1, a.qkv.weight, a.qkv.bias)
         idx, inv, interp = self._idx(x.device)
         cfg = dict(B=Bp, N=N, H=a.num_heads, D=hd, thw=p["thw"], eps=self.eps, stride_q=p["stride_q"],
@@ -139,7 +142,7 @@ class _Block(nn.Module):
             x = Fn.stochastic_depth_add(xs, Fn.linear(att, a.project[0].weight, a.project[0].bias), self.sd_prob, Bp)
         else:
             x = Fn.linear(att, a.project[0].weight, a.project[0].bias, residual=xs)
-        xn2 = Fn.layernorm(x, self.norm2.weight, self.norm2.bias, self.eps)
+        xn2, x = Fn.layernorm_skip(x, self.norm2.weight, self.norm2.bias, self.eps)  # x also is the MLP's residual
         if drop:
             return Fn.stochastic_depth_add(x, Fn.mlp(xn2, self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight,
                                                      self.mlp[3].bias), self.sd_prob, Bp)

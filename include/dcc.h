@@ -93,9 +93,11 @@ int dcc_relpos_kaug(void* Kf, const int* dims, const int64_t* strides, int dtype
  * attention pool (models/video_aggregator.py:15,24,99; models/attention_pool.py:53,94). */
 int dcc_layernorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
                       float* mean, float* rstd, int64_t rows, int C, float eps, int dtype, void* stream);
+/* dres (nullable, dx's type and leading dimension): gradient reaching x through its OTHER use in a transformer block
+ * (the residual / skip branch), added into dx here instead of by a separate autograd add kernel. */
 int dcc_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean, const float* rstd,
-                      const float* gamma, void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int C,
-                      int dtype, int grad_dtype, void* stream);
+                      const float* gamma, void* dx, int64_t lddx, float* dgamma, float* dbeta, const void* dres,
+                      int64_t rows, int C, int dtype, int grad_dtype, void* stream);
 
 /* ---- convolution-shaped ops (csrc/conv.hip) ------------------------------------------------
  * dcc_im2col3d: operand of the conv_proj GEMM; video is NDHWC fp32 as produced by the permute+view of

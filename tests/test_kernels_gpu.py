@@ -231,3 +231,31 @@ def test_nan_to_num_and_dropout():
     assert abs(kept - 0.75) < 5e-3
     assert torch.allclose(m[m != 0], torch.tensor(1 / 0.75, device="cuda"))
     assert torch.equal(m, K.dropout(y, 0.25, seed=123)) and not torch.equal(m, K.dropout(y, 0.25, seed=124))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+def test_layernorm_skip_sums_both_gradients(dtype, tol):
+    """(LN(x), x): the gradient of the residual use of x is added inside the LayerNorm-backward kernel."""
+    from deepcoro_clip_amd import functional as Fn
+
+    g = _gen(21)
+    rows, C = 777, 384
+    x0 = (torch.randn(rows, C, generator=g) * 1.5).to(dtype).float()
+    gam0, bet0 = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    d1, d2 = torch.randn(rows, C, generator=g).to(dtype).float(), torch.randn(rows, C, generator=g).to(dtype).float()
+    xr, gr, br = x0.clone().requires_grad_(True), gam0.clone().requires_grad_(True), bet0.clone().requires_grad_(True)
+    (F.layer_norm(xr, (C,), gr, br, 1e-6) * d1 + xr * d2).sum().backward()
+    x = x0.cuda().to(dtype).requires_grad_(True)
+    gam, bet = gam0.cuda().requires_grad_(True), bet0.cuda().requires_grad_(True)
+    y, xs = Fn.layernorm_skip(x, gam, bet, 1e-6)
+    torch.autograd.backward([y, xs], [d1.cuda().to(dtype), d2.cuda().to(dtype)])
+    assert torch.equal(xs, x)
+    assert _rel(x.grad.float(), xr.grad) < tol
+    assert _rel(gam.grad, gr.grad) < tol and _rel(bet.grad, br.grad) < tol
+    # only one of the two outputs used downstream: the missing gradient counts as zero
+    x2 = x0.cuda().to(dtype).requires_grad_(True)
+    y2, _ = Fn.layernorm_skip(x2, gam, bet, 1e-6)
+    y2.backward(d1.cuda().to(dtype))
+    xr2 = x0.clone().requires_grad_(True)
+    F.layer_norm(xr2, (C,), gam0, bet0, 1e-6).backward(d1)
+    assert _rel(x2.grad.float(), xr2.grad) < tol
