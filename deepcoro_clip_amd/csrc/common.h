@@ -96,7 +96,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // instead of libm erff's ~40 instructions; GELU sits in GEMM epilogues where VALU time is on the critical path.
 __device__ __forceinline__ float erf_fast(float x, float* exp_mx2) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);  // bare v_rcp_f32 (1 ulp); __frcp_rn expands to a full IEEE division
   const float e = __expf(-ax * ax);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float r = 1.0f - poly * e;

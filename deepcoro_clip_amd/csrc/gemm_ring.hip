@@ -17,6 +17,7 @@
 // the first D K-steps after an epilogue may leave them outstanding (+E on the immediate; E is a lower bound of the
 // stores issued, rounded down to the immediates compiled in).
 #include "gemm_params.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -64,10 +65,14 @@ struct Geo {  // launch-constant geometry
 #ifdef DCC_RING_PROFILE
 __device__ unsigned long long g_prof[8];  // [0] consumer barrier wait, [1] MFMA section, [2] epilogue, [3] steps, [4] loader vm wait, [5] loader barrier, [6] loader issue
 #define PROF_T() __builtin_amdgcn_s_memtime()
-#define PROF_ADD(i, v) do { if (lane == 0 && (wave == 0 || wave == 4)) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
+#define PROF_DECL unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_ADD(i, v) prof_acc[i] += (unsigned long long)(v)
+#define PROF_FLUSH() do { if (lane == 0 && (wave == 0 || wave == 4)) { for (int i_ = 0; i_ < 8; ++i_) if (prof_acc[i_]) atomicAdd(&g_prof[i_], prof_acc[i_]); } } while (0)
 #else
 #define PROF_T() 0ull
+#define PROF_DECL
 #define PROF_ADD(i, v) do { } while (0)
+#define PROF_FLUSH() do { } while (0)
 #endif
 
 template <typename TC, bool A_KM, bool B_KM, int NS>
@@ -76,6 +81,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  PROF_DECL;
   const bool loader = wave >= 4;           // waves 4.. only move data; waves 0..3 only do MFMA + epilogue
   const int w4 = wave & 3;                 // consumer index
   const int lw = wave - 4;                 // loader index
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
       issue();
       PROF_ADD(4, t1 - t0); PROF_ADD(5, t2 - t1); PROF_ADD(6, PROF_T() - t2);
     }
+    PROF_FLUSH();
     return;
   }
 
@@ -363,6 +370,260 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
     }
     ++q;
   }
+  PROF_FLUSH();
+}
+
+// =====================================================================================================
+// Ring kernel with an epilogue crew (bf16 output, no split-K): the towers' K = 96..1536 GEMMs spend as long in the
+// epilogue (bias / GELU / residual / 32 KB of stores per tile) as in their 2..24 K-steps, and 4 MFMA waves doing that
+// serially left the matrix cores idle half of the time.  Here a workgroup has three crews of 4 waves:
+//   consumers  MFMA only.  One barrier after a tile's last K-step they add the bias, round to bf16 and drop the tile
+//              into an LDS mailbox (C^T accumulators: the MFMA runs with swapped operands so that a lane holds 4
+//              consecutive columns of one row -> 8-byte LDS writes), then carry on with the next tile;
+//   loaders    LDS-DMA ring as above (NS = 3 stages);
+//   storers    pick the mailbox up, in row slices spread over the NEXT tile's K-steps: saved pre-activation, GELU,
+//              GELU', residual and full 256-byte-row stores all happen here, under the consumers' MFMAs.
+// All 12 waves meet at ONE barrier per K-step (+2 at the end); the mailbox hand-offs ride on those barriers.
+// Non-linear epilogues see the bf16-rounded linear output (what an unfused bf16 Linear -> GELU / + residual sees).
+constexpr int MB_PITCH = 2 * BMN + 16;         // mailbox row pitch (bytes): 16-byte aligned rows, 8-byte writes 2-way at worst
+constexpr int MB_B = BMN * MB_PITCH;
+constexpr int NS2 = 3;
+constexpr int NT2 = 64 * 12;
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo geo) {
+  constexpr int NS = NS2, D = NS - 1, PPL = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* mbox = smem + NS * STAGE_B;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2;  // 0 consumers, 1 loaders, 2 storers
+  const int w4 = wave & 3;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int item0 = (bid & 7) * (G >> 3) + (bid >> 3);
+
+  struct Item { int idx, m0, n0, bz; };
+  auto locate = [&](int idx) {
+    Item it;
+    it.idx = idx;
+    it.m0 = it.n0 = it.bz = 0;
+    if (idx < geo.items) {
+      const int z = idx / geo.tiles, t = idx - z * geo.tiles;
+      const int tm = t / geo.tilesN, tn = t - tm * geo.tilesN;
+      it.m0 = tm * BMN; it.n0 = tn * BMN; it.bz = z;
+    }
+    return it;
+  };
+  const int nk = geo.ksteps;  // no split-K: every item walks all K-steps (>= 2)
+  int nitems = 0;
+  for (int i = item0; i < geo.items; i += G) ++nitems;
+  const int S = nitems * nk;  // K-steps of this workgroup; every wave passes S + 2 barriers
+
+  if (role == 1) {
+    // ================================================================================================ loaders
+    int voffA[PPL], voffB[PPL], kcA[PPL], kcB[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const int g = w4 * PPL + j;
+      kcA[j] = kcB[j] = 0;
+      if (A_KM) { const int R = g * 4 + (lane >> 4), c = (lane & 15) ^ swz_km128(R); voffA[j] = (R * (int)p.lda + c * 8) * 2; }
+      else { const int R = g * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7); voffA[j] = (R * (int)p.lda + c * 8) * 2; kcA[j] = c * 8; }
+      if (B_KM) { const int R = g * 4 + (lane >> 4), c = (lane & 15) ^ swz_km128(R); voffB[j] = (R * (int)p.ldb + c * 8) * 2; }
+      else { const int R = g * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7); voffB[j] = (R * (int)p.ldb + c * 8) * 2; kcB[j] = c * 8; }
+    }
+    constexpr int OOB = 0x7fffff00;
+    const int voffBias = ((w4 & 1) * 64 + lane) * 4;
+    const int kstrideA = A_KM ? BK * (int)p.lda * 2 : BK * 2;
+    const int kstrideB = B_KM ? BK * (int)p.ldb * 2 : BK * 2;
+    auto bytes_left = [](bool km, int64_t ld, int rem, int K) -> unsigned {
+      const int64_t elems = rem <= 0 ? 0 : (km ? (int64_t)(K - 1) * ld + rem : (int64_t)(rem - 1) * ld + K);
+      return (unsigned)(elems * 2);
+    };
+    Item L = locate(item0);
+    int l_kt = 0, issued = 0;
+    __amdgpu_buffer_rsrc_t rsA, rsB, rsBias;
+    auto bind = [&]() {
+      if (L.idx >= geo.items) return;
+      const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (int64_t)L.bz * p.sA + (A_KM ? (int64_t)L.m0 : (int64_t)L.m0 * p.lda);
+      const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (int64_t)L.bz * p.sB + (B_KM ? (int64_t)L.n0 : (int64_t)L.n0 * p.ldb);
+      rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, bytes_left(A_KM, p.lda, p.M - L.m0, p.K), 0x00020000);
+      rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, bytes_left(B_KM, p.ldb, p.N - L.n0, p.K), 0x00020000);
+      const bool hb = (p.flags & GEMM_BIAS) != 0;
+      rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb ? p.bias + L.n0 : (const float*)p.A), 0,
+                                                 hb ? (unsigned)((p.N - L.n0) * 4) : 0u, 0x00020000);
+    };
+    bind();
+    auto issue = [&]() {
+      if (L.idx >= geo.items) return;
+      char* st = smem + (issued % NS) * STAGE_B;
+      const int k0 = l_kt * BK;
+      const int soA = l_kt * kstrideA, soB = l_kt * kstrideB;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const int vo = (!A_KM && k0 + kcA[j] >= p.K) ? OOB : voffA[j] + soA;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, st + (w4 * PPL + j) * 1024), 16, vo, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const int vo = (!B_KM && k0 + kcB[j] >= p.K) ? OOB : voffB[j] + soB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, st + TILE_B + (w4 * PPL + j) * 1024), 16, vo, 0, 0, 0);
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LDS_PTR(void, st + 2 * TILE_B + (w4 & 1) * 256), 4, voffBias, 0, 0, 0);
+      ++issued;
+      if (++l_kt == nk) { L = locate(L.idx + G); l_kt = 0; bind(); }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue();
+    for (int q = 0; q < S + 2; ++q) {
+      if (q < S) {
+        if (issued - (q + 1) >= D - 1) wait_vm<(D - 1) * (2 * PPL + 1)>();
+        else wait_vm<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if (q < S) issue();
+    }
+    return;
+  }
+
+  if (role == 0) {
+    // ============================================================================================== consumers
+    const int wr = w4 >> 1, wc = w4 & 1, h = lane >> 5;
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    };
+    zero_acc();
+    f32x4 bias4[2][4];  // bias of this lane's columns, fetched during the tile's last K-step (its ring stage is recycled at the next barrier)
+    bool pending = false;
+    int kt = 0;
+    for (int q = 0; q < S + 2; ++q) {
+      __builtin_amdgcn_s_barrier();
+      if (pending) {
+        // tile finished one step ago: alpha * acc + bias -> bf16 -> mailbox (row m, 4 consecutive columns per write)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            char* rowp = mbox + (wr * 64 + 32 * i + (lane & 31)) * MB_PITCH + (wc * 64 + 32 * j + 4 * h) * 2;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              bf16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[i][j][4 * g4 + e] * p.alpha + bias4[j][g4][e]);
+              *reinterpret_cast<bf16x4*>(rowp + 16 * g4) = o;
+            }
+          }
+        zero_acc();
+        pending = false;
+      }
+      if (q >= S) continue;
+      const char* sa = smem + (q % NS) * STAGE_B;
+      const char* sb = sa + TILE_B;
+      bf16x8 fa[2][2], fb[2][2];
+      auto fetch = [&](int buf, int s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[buf][i] = A_KM ? frag_km(sa, wr * 64 + 32 * i, s, lane) : frag_kc(sa, wr * 64 + 32 * i, s, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[buf][j] = B_KM ? frag_km(sb, wc * 64 + 32 * j, s, lane) : frag_kc(sb, wc * 64 + 32 * j, s, lane);
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < BK / 16) fetch(cur ^ 1, s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // swapped operands: the accumulator tile is C^T (rows = n on registers, columns = m on lanes)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fb[cur][j], fa[cur][i], acc[i][j]);
+      }
+      if (++kt == nk) {
+        kt = 0;
+        pending = true;
+        const float* biasl = reinterpret_cast<const float*>(sa + 2 * TILE_B);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) bias4[j][g4] = *reinterpret_cast<const f32x4*>(biasl + wc * 64 + 32 * j + 8 * g4 + 4 * h);
+      }
+    }
+    return;
+  }
+
+  // ================================================================================================== storers
+  // tile dumped after barrier q_d is readable after barrier q_d + 1 and must be drained before the next dump at
+  // q_d + nk: slices over the nk - 1 steps in between (the last tile: everything in the one remaining step).
+  // A wave owns the 8 row groups {16 k + 4 w4 .. + 3}; the residual / GELU' operand of all 8 is requested at step q_d
+  // (while the tile is being dumped), one K-step before the first slice needs it.
+  {
+    Item cur = locate(item0);
+    int done_items = 0;
+    const int c8 = (lane & 15) * 8;
+    const bool want_x = (p.flags & (GEMM_RESID | GEMM_DGELU)) != 0;
+    const bf16_t* X = reinterpret_cast<const bf16_t*>((p.flags & GEMM_RESID) ? p.R : p.aux);
+    const int64_t ldxx = (p.flags & GEMM_RESID) ? p.ldr : p.ldaux;
+    bf16x8 pre[8];
+    for (int q = 0; q < S + 2; ++q) {
+      __builtin_amdgcn_s_barrier();
+      const int t = done_items;
+      if (t >= nitems) continue;
+      const int qd = (t + 1) * nk;
+      if (q == qd && want_x) {
+        const int col = cur.n0 + c8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int row = cur.m0 + 16 * k + 4 * w4 + (lane >> 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pre[k][e] = (bf16_t)0.0f;
+          if (row < p.M && col < p.N) pre[k] = *reinterpret_cast<const bf16x8*>(X + (int64_t)row * ldxx + col);
+        }
+      }
+      const bool last = (t + 1 == nitems);
+      const int avail = last ? 1 : (nk - 1 < 8 ? nk - 1 : 8);
+      const int sl = q - (qd + 1);
+      if (sl < 0 || sl >= avail) continue;
+      const int k0 = (8 * sl) / avail, k1 = (8 * (sl + 1)) / avail;
+      bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + (int64_t)cur.bz * p.sC;
+      const int col = cur.n0 + c8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k < k0 || k >= k1) continue;
+        const int r = 16 * k + 4 * w4 + (lane >> 4);
+        const int row = cur.m0 + r;
+        const bf16x8 mv = *reinterpret_cast<const bf16x8*>(mbox + r * MB_PITCH + c8 * 2);
+        if (row >= p.M || col >= p.N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)mv[e];
+        if (p.flags & GEMM_SAVE_PRE) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col) = mv;
+        if (p.flags & GEMM_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        }
+        if (p.flags & GEMM_DGELU) {
+          bf16x8 a = pre[k];
+          if (p.flags & GEMM_RESID) a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)a[e]);
+        }
+        if (p.flags & GEMM_RESID) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)pre[k][e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+        *reinterpret_cast<bf16x8*>(C + (int64_t)row * p.ldc + col) = o;
+      }
+      if (sl + 1 == avail) { ++done_items; cur = locate(cur.idx + G); }
+    }
+  }
 }
 
 int num_cus() {
@@ -425,6 +686,30 @@ int dcc_gemm_ring_launch(const GemmParams& p, int a_km, int b_km, int out_dtype,
   geo.items = (int)items;
   geo.ksteps = (p.K + BK - 1) / BK;
   geo.per = (geo.ksteps + p.splitk - 1) / p.splitk;
+  if (out_dtype == DCC_BF16 && p.splitk == 1 && !(p.flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && geo.ksteps >= 2 &&
+      !getenv("DCC_RING_V1")) {
+    constexpr int LDS2 = NS2 * STAGE_B + MB_B;
+#define RING2(AK, BK_)                                                                                              \
+  do {                                                                                                              \
+    auto kern = gemm_ring2_kernel<AK, BK_>;                                                                         \
+    static bool cfg = false;                                                                                        \
+    if (!cfg) {                                                                                                     \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return DCC_ERR_LAUNCH; \
+      cfg = true;                                                                                                   \
+    }                                                                                                               \
+    int G = num_cus() & ~7;                                                                                         \
+    if (G < 8) G = 8;                                                                                               \
+    const int need = (geo.items + 7) & ~7;                                                                          \
+    if (G > need) G = need;                                                                                         \
+    hipLaunchKernelGGL(kern, dim3(G), dim3(NT2), LDS2, st, p, geo);                                                 \
+    return dcc_check_launch();                                                                                      \
+  } while (0)
+    if (!a_km && !b_km) RING2(false, false);
+    if (!a_km && b_km) RING2(false, true);
+    if (a_km && !b_km) RING2(true, false);
+    RING2(true, true);
+#undef RING2
+  }
 #define RING(TC_)                                                                   \
   do {                                                                              \
     if (!a_km && !b_km) return launch<TC_, false, false>(p, geo, st);               \
