@@ -227,8 +227,13 @@ def main():
             s = summ[fam]
             achieved = s["units"] / (s["ms"] * 1e-3) / 1e12
             peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
-            roofline = {"bound": "mfma", "kernel": "gemm_kernel<" + args.dtype + ">", "achieved": round(achieved, 2),
-                        "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            traffic = None  # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process)
+            pmc = os.path.join(ROOT, "profiles", "r01_c_pmc_gemm_traffic.json")
+            if os.path.exists(pmc) and args.dtype == "bf16" and args.batch == 24 and args.videos == 1 and world == 1:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            roofline = {"bound": "mfma", "kernel": "gemm_ring_kernel / gemm_kernel <" + args.dtype + ">", "achieved": round(achieved, 2),
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": round(s["bytes"] / max(1, s["launches"])),
                         "launches_per_step": s["launches"] // args.steps,
                         "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 2),
                         "gflop_per_step": round(s["units"] / args.steps / 1e9, 1),

@@ -26,14 +26,14 @@ class KernelTimer:
     def __init__(self):
         self.records: dict[str, list] = {}
 
-    def time(self, family: str, units: float, label: str = ""):
-        return _TimerCtx(self, family, units, label)
+    def time(self, family: str, units: float, label: str = "", nbytes: float = 0.0):
+        return _TimerCtx(self, family, units, label, nbytes)
 
     def by_label(self) -> list:
         """[(family, label, launches, ms, units)] sorted by time (call after summary(), which synchronises)."""
         agg: dict = {}
         for fam, recs in self.records.items():
-            for a, b, u, lab in recs:
+            for a, b, u, lab, _nb in recs:
                 k = (fam, lab)
                 c = agg.setdefault(k, [0, 0.0, 0.0])
                 c[0] += 1
@@ -47,13 +47,13 @@ class KernelTimer:
         for fam, recs in self.records.items():
             ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             units = sum(r[2] for r in recs)
-            out[fam] = {"launches": len(recs), "ms": ms, "units": units}
+            out[fam] = {"launches": len(recs), "ms": ms, "units": units, "bytes": sum(r[4] for r in recs)}
         return out
 
 
 class _TimerCtx:
-    def __init__(self, timer, family, units, label=""):
-        self.t, self.f, self.u, self.l = timer, family, units, label
+    def __init__(self, timer, family, units, label="", nbytes=0.0):
+        self.t, self.f, self.u, self.l, self.nb = timer, family, units, label, nbytes
 
     def __enter__(self):
         self.a = torch.cuda.Event(enable_timing=True)
@@ -62,7 +62,7 @@ class _TimerCtx:
 
     def __exit__(self, *exc):
         self.b.record()
-        self.t.records.setdefault(self.f, []).append((self.a, self.b, self.u, self.l))
+        self.t.records.setdefault(self.f, []).append((self.a, self.b, self.u, self.l, self.nb))
 
 
 TIMER: KernelTimer | None = None  # set by bench.py for the instrumented pass only
@@ -79,8 +79,8 @@ class _NoCtx:
 _NOCTX = _NoCtx()
 
 
-def _timed(family: str, units: float, label: str = ""):
-    return TIMER.time(family, units, label) if TIMER is not None else _NOCTX
+def _timed(family: str, units: float, label: str = "", nbytes: float = 0.0):
+    return TIMER.time(family, units, label, nbytes) if TIMER is not None else _NOCTX
 
 
 def _i64(vals):
@@ -136,8 +136,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
         assert a_km and colsum.dtype == torch.float32 and colsum.numel() == M
         flags |= GEMM_COLSUM_A
     flags |= GEMM_VARIANT
+    # algorithmic HBM bytes: every operand once, the output once (read-modify-write when accumulating)
+    osz = out.element_size()
+    nbytes = (M * K + N * K) * a.element_size() + M * N * osz * (2 if accumulate else 1)
+    nbytes += M * N * osz * (int(resid is not None) + int(save_pre)) + M * N * a.element_size() * int(dgelu)
     with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K,
-                f"M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk} f{flags} out{out.dtype}"):
+                f"M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk} f{flags} out{out.dtype}", nbytes):
         L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), L.ptr(resid), L.ptr(aux), L.ptr(colsum),
                a.stride(0), b.stride(0), out.stride(0), resid.stride(0) if resid is not None else 0,
                aux.stride(0) if aux is not None else 0, M, N, K, 1, 0, 0, 0, splitk, float(alpha), flags, int(a_km),
@@ -150,8 +154,9 @@ def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=N
     """Raw batched form (base tensors + explicit strides); `a`/`b`/`out` only provide base pointers and dtypes."""
     L.require_cuda(a, b, out, bias)
     flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_ACCUM if accumulate else 0) | GEMM_VARIANT
+    nbytes = batch * ((M * K + N * K) * a.element_size() + M * N * out.element_size() * (2 if accumulate else 1))
     with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * batch,
-                f"batched{batch} M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk}"):
+                f"batched{batch} M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk}", nbytes):
         L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), None, None, None, lda, ldb, ldc, 0, 0, M, N, K, batch,
                sA, sB, sC, splitk, float(alpha), flags, int(a_km), int(b_km), L.dt(a), L.dt(out), L.stream())
     return out
