@@ -292,6 +292,32 @@ def relpos_aug_width(k_thw) -> int:
     return 32 * ((need + 31) // 32)
 
 
+_BRANCH_STREAMS: dict = {}
+_USE_BRANCH_STREAMS = __import__("os").environ.get("DCC_BRANCH_STREAMS", "1") != "0"
+
+
+class _Branches:
+    """Run the independent q / k / v pooling branches of an MViT block on three HIP streams (the current one + two
+    cached side streams): their kernels are bound by memory latency at modest occupancy, so they overlap almost for
+    free.  Fork: the side streams wait for the current stream; join: the current stream waits for them."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        key = str(device)
+        if key not in _BRANCH_STREAMS:
+            _BRANCH_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(2)]
+        self.side = _BRANCH_STREAMS[key] if _USE_BRANCH_STREAMS else []
+        for s in self.side:
+            s.wait_stream(self.main)
+
+    def stream(self, i: int):
+        return torch.cuda.stream(self.side[i - 1]) if (i > 0 and self.side) else torch.cuda.stream(self.main)
+
+    def join(self):
+        for s in self.side:
+            self.main.wait_stream(s)
+
+
 class MvitAttnCoreFn(torch.autograd.Function):
     """qkv -> Pool(q,k,v) (dw conv3d + LayerNorm) -> [3-D RoPE] -> rel-pos tables -> flash attention (+ residual pool).
 
@@ -308,21 +334,26 @@ class MvitAttnCoreFn(torch.autograd.Function):
         qkv5 = qkv.view(B, N, 3, H, D)
         geo = {}
         conv = {}
-        for name, idx, w, stride in (("q", 0, wq, cfg["stride_q"]), ("k", 1, wk, cfg["stride_kv"]), ("v", 2, wv, cfg["stride_kv"])):
-            g = K.PoolGeom(B, H, D, tuple(thw), (3, 3, 3), tuple(stride), (1, 1, 1), True)
-            geo[name] = g
-            w27 = w.detach().reshape(D, 27)
-            conv[name], _ = K.pool_fwd(qkv5[:, :, idx], g, w27)
+        for name, stride in (("q", cfg["stride_q"]), ("k", cfg["stride_kv"]), ("v", cfg["stride_kv"])):
+            geo[name] = K.PoolGeom(B, H, D, tuple(thw), (3, 3, 3), tuple(stride), (1, 1, 1), True)
         q_thw, k_thw = geo["q"].out_thw, geo["k"].out_thw
         Nq, Nk = geo["q"].n_out, geo["k"].n_out
         A = relpos_aug_width(k_thw)
         DQK = D + A
         Qf = torch.empty((B, Nq, H, DQK), device=qkv.device, dtype=dt)
         Kf = torch.empty((B, Nk, H, DQK), device=qkv.device, dtype=dt)
-        _, mq, rq = K.layernorm_fwd(conv["q"].view(-1, D), gq.detach(), bq.detach(), eps, out=Qf.view(-1, DQK)[:, :D])
-        _, mk, rk = K.layernorm_fwd(conv["k"].view(-1, D), gk.detach(), bk.detach(), eps, out=Kf.view(-1, DQK)[:, :D])
-        Vn, mv, rv = K.layernorm_fwd(conv["v"].view(-1, D), gv.detach(), bv.detach(), eps)
-        Vn = Vn.view(B, Nk, H, D)
+        Vn = torch.empty((B, Nk, H, D), device=qkv.device, dtype=dt)
+        stats = {}
+        br = _Branches(qkv.device)
+        for i, (name, w, gam, bet, dst) in enumerate((("q", wq, gq, bq, Qf.view(-1, DQK)[:, :D]),
+                                                      ("k", wk, gk, bk, Kf.view(-1, DQK)[:, :D]),
+                                                      ("v", wv, gv, bv, Vn.view(-1, D)))):
+            with br.stream(i):
+                conv[name], _ = K.pool_fwd(qkv5[:, :, i], geo[name], w.detach().reshape(D, 27))
+                _, m_, r_ = K.layernorm_fwd(conv[name].view(-1, D), gam.detach(), bet.detach(), eps, out=dst)
+                stats[name] = (m_, r_)
+        br.join()
+        (mq, rq), (mk, rk), (mv, rv) = stats["q"], stats["k"], stats["v"]
         rope = cfg.get("rope")
         if rope is not None:
             K.rope(Qf[..., :D], Qf[..., :D], rope["cos_q"], rope["sin_q"])
@@ -386,6 +417,7 @@ class MvitAttnCoreFn(torch.autograd.Function):
         grads = {}
         small = zeros_f32((3, 2, D), dev)  # LayerNorm gamma/beta gradients of the q, k, v pools
         small_w = zeros_f32((3, D, 27), dev)
+        br = _Branches(dev)
         for name, i, dy4, conv, mean, rstd, gam, w in (("q", 0, dq, cq, mq, rq, gq, wq), ("k", 1, dk, ck, mk, rk, gk, wk),
                                                          ("v", 2, dVn, cv, mv, rv, gv, wv)):
             g = geo[name]
@@ -395,12 +427,14 @@ class MvitAttnCoreFn(torch.autograd.Function):
             else:  # dk is a column slice of the [.., DQK] buffer: rows are strided by DQK
                 dy2 = dy4.as_strided((rows, D), (dy4.stride(2), 1), dy4.storage_offset())
             dgam, dbet = small[i, 0], small[i, 1]
-            dconv = K.layernorm_bwd(dy2, conv.view(rows, D), mean, rstd, gam, dgam, dbet)
-            dconv4 = dconv.view(B, g.n_out, H, D)
-            K.pool_bwd_data(dconv4, dqkv[:, :, i], g, w.reshape(D, 27))
             dw = small_w[i]
-            K.dwconv_bwd_weight(dconv4, qkv.view(B, N, 3, H, D)[:, :, i], g, dw)
+            with br.stream(i):  # LayerNorm backward -> pool data gradient + pool weight gradient, one stream per branch
+                dconv = K.layernorm_bwd(dy2, conv.view(rows, D), mean, rstd, gam, dgam, dbet)
+                dconv4 = dconv.view(B, g.n_out, H, D)
+                K.pool_bwd_data(dconv4, dqkv[:, :, i], g, w.reshape(D, 27))
+                K.dwconv_bwd_weight(dconv4, qkv.view(B, N, 3, H, D)[:, :, i], g, dw)
             grads[name] = (dw.view(D, 1, 3, 3, 3), dgam, dbet)
+        br.join()
         return (dqkv.view(B * N, 3 * H * D), grads["q"][0], grads["k"][0], grads["v"][0], grads["q"][1], grads["q"][2],
                 grads["k"][1], grads["k"][2], grads["v"][1], grads["v"][2], drel[0], drel[1], drel[2], None)
 
