@@ -535,6 +535,17 @@ def dropout(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
     return out
 
 
+def retrieval_ranks(sim: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """sim fp32 [Nq, Nc] (unit inner stride), gt int32 [Nq, G] (-1 = empty) -> int32 [Nq, G] 1-based ranks (0 = empty)."""
+    L.require_cuda(sim, gt)
+    assert sim.dim() == 2 and sim.dtype == torch.float32 and sim.stride(1) == 1
+    assert gt.dim() == 2 and gt.dtype == torch.int32 and gt.is_contiguous() and gt.shape[0] == sim.shape[0]
+    ranks = torch.empty_like(gt)
+    L.call("dcc_retrieval_ranks", L.ptr(sim), sim.stride(0), L.ptr(gt), L.ptr(ranks), sim.shape[0], sim.shape[1], gt.shape[1],
+           L.stream())
+    return ranks
+
+
 # ----------------------------------------------------------------------------------------- loss
 def l2norm_fwd(x: torch.Tensor, eps: float = 1e-12, norm_sum: torch.Tensor | None = None):
     L.require_cuda(x, norm_sum)

@@ -1,15 +1,15 @@
 """Retrieval metrics with the reference's function names and return types (utils/retrieval_metrics.py:65-324).
 
-These run once per epoch on rank 0 over [Nv, Mt] similarities ("next" row); the rank computation here
-is host-side integer logic on the similarity matrix copied back once (no per-element `.item()` loops as in the
-reference).  The per-step diagnostics (`compute_embedding_norms`, alignment) come out of the fused loss kernels
+These run once per epoch on rank 0 over [Nv, Mt] similarities.  The similarity GEMM and the
+rank of every ground-truth candidate are computed on the GPU (`dcc_gemm`, `dcc_retrieval_ranks`: integer-exact
+positions in the stable descending order the reference obtains by sorting); the host only combines those few integers
+(`*_from_ranks`, no `.item()` loops over the matrix as in the reference).  The per-step diagnostics (`compute_embedding_norms`, alignment) come out of the fused loss kernels
 instead (runner.py)."""
 from __future__ import annotations
 
 import math
 from typing import Iterable, List, Sequence, Set, Union
 
-import numpy as np
 import torch
 
 
@@ -40,51 +40,79 @@ def _normalize_ground_truth_sets(ground_truth_indices, num_queries: int) -> List
     return cleaned if cleaned else [set() for _ in range(num_queries)]
 
 
-def _order(similarity_matrix: torch.Tensor) -> np.ndarray:
-    """Descending candidate order per query (ties by index, like a stable descending argsort)."""
-    sim = similarity_matrix.detach().float().cpu().numpy().astype(np.float64)
-    return np.argsort(-sim, axis=1, kind="stable")
+def gt_ranks(similarity_matrix: torch.Tensor, gt_sets: List[Set[int]]) -> List[List[int]]:
+    """Sorted 1-based ranks of every ground-truth candidate of every query in the stable descending order of its
+    similarity row, computed on the GPU (`dcc_retrieval_ranks`): one small [Nq, G] int tensor comes back instead of
+    the [Nq, Mt] matrix.  Everything below is integer / float arithmetic on these few numbers."""
+    from . import kernels as K
 
-
-def _best_ranks(order: np.ndarray, gt_sets, num_candidates):
-    ranks = []
+    n_q, n_c = similarity_matrix.shape
+    G = max(1, max((len(s) for s in gt_sets), default=1))
+    table = torch.full((n_q, G), -1, dtype=torch.int32)
     for i, s in enumerate(gt_sets):
-        best = None
-        if s:
-            inv = np.empty(order.shape[1], dtype=np.int64)
-            inv[order[i]] = np.arange(order.shape[1])
-            pos = [int(inv[g]) + 1 for g in s if 0 <= g < num_candidates]
-            best = min(pos) if pos else None
-        ranks.append(best)
-    return ranks
+        valid = sorted(g for g in s if 0 <= g < n_c)
+        if valid:
+            table[i, :len(valid)] = torch.tensor(valid, dtype=torch.int32)
+    sim = similarity_matrix.detach()
+    if sim.dtype != torch.float32:
+        sim = K.cast(sim.contiguous(), torch.float32)
+    if sim.stride(1) != 1:
+        sim = sim.contiguous()
+    ranks = K.retrieval_ranks(sim, table.to(sim.device)).cpu()
+    return [sorted(int(r) for r in row if r > 0) for row in ranks.tolist()]
+
+
+def recall_from_ranks(ranks: List[List[int]], k: int) -> float:
+    hits = [1.0 if (r and r[0] <= k) else 0.0 for r in ranks]
+    return float(sum(hits) / len(hits)) if hits else 0.0
+
+
+def mrr_from_ranks(ranks: List[List[int]]) -> float:
+    vals = [1.0 / r[0] if r else 0.0 for r in ranks]
+    return sum(vals) / len(vals) if vals else 0.0
+
+
+def ndcg_from_ranks(ranks: List[List[int]], gt_sizes: List[int], k: int) -> List[float]:
+    vals = []
+    for r, n in zip(ranks, gt_sizes):
+        if n == 0:
+            vals.append(0.0)
+            continue
+        dcg = sum(1.0 / math.log2(x + 1) for x in r if x <= k)  # position x-1 in the reference's 0-based loop
+        idcg = sum(1.0 / math.log2(j + 2) for j in range(min(n, k)))
+        vals.append(dcg / idcg if idcg > 0 else 0.0)
+    return vals
+
+
+def ap_from_ranks(ranks: List[List[int]]) -> List[float]:
+    return [sum((h + 1) / x for h, x in enumerate(r)) / len(r) if r else 0.0 for r in ranks]
 
 
 def compute_recall_at_k(similarity_matrix: torch.Tensor, global_gt_indices, k_values: List[int] = [1, 5]) -> dict:
     gt_sets = _normalize_ground_truth_sets(global_gt_indices, similarity_matrix.size(0))
-    order = _order(similarity_matrix)
+    ranks = gt_ranks(similarity_matrix, gt_sets)
     n_cand = similarity_matrix.size(1)
     metrics = {}
     for k in k_values:
-        k_use = min(k, n_cand)
         if n_cand < k:
             print(f"Warning: similarity matrix has only {n_cand} candidates; adjusting Recall@{k} to Recall@{n_cand}.")
-        hits = [1.0 if (s and any(int(j) in s for j in order[i, :k_use])) else 0.0 for i, s in enumerate(gt_sets)]
-        metrics[f"Recall@{k}"] = float(sum(hits) / len(hits)) if hits else 0.0
+        metrics[f"Recall@{k}"] = recall_from_ranks(ranks, min(k, n_cand))
     return metrics
 
 
 def compute_mrr(similarity_matrix: torch.Tensor, global_gt_indices) -> dict:
+    from . import kernels as K
+
     if similarity_matrix.dim() != 2:
         print(f"Warning: similarity_matrix has {similarity_matrix.dim()} dimensions, expected 2")
         return {"MRR_V2T": 0.0}
     n_v, n_t = similarity_matrix.shape
-    sim = torch.nan_to_num(similarity_matrix.detach().float().cpu(), nan=0.0, posinf=1e4, neginf=-1e4)
     if n_t == 1:
         return {"MRR_V2T": 1.0}
+    sim = similarity_matrix.detach().float().contiguous().clone()
+    K.nan_to_num_(sim, 0.0, 1e4, -1e4)  # utils/retrieval_metrics.py:117-121
     gt_sets = _normalize_ground_truth_sets(global_gt_indices, n_v)
-    ranks = _best_ranks(_order(sim), gt_sets, n_t)
-    vals = [0.0 if r is None else 1.0 / r for r in ranks]
-    return {"MRR_V2T": sum(vals) / len(vals) if vals else 0.0}
+    return {"MRR_V2T": mrr_from_ranks(gt_ranks(sim, gt_sets))}
 
 
 def compute_similarity_matrix(video_features: torch.Tensor, text_features: torch.Tensor) -> torch.Tensor:
@@ -123,21 +151,9 @@ def compute_ndcg_at_k(similarity_matrix: torch.Tensor, global_gt_indices, k_valu
     if n_q == 0:
         return {}
     gt_sets = _normalize_ground_truth_sets(global_gt_indices, n_q)
-    order = _order(similarity_matrix)
-    metrics = {}
-    for k in k_values:
-        ek = min(k, n_c)
-        vals = []
-        for i, s in enumerate(gt_sets):
-            if not s:
-                vals.append(0.0)
-                continue
-            dcg = sum(1.0 / math.log2(r + 2) for r in range(ek) if int(order[i, r]) in s)
-            ideal = min(len(s), ek)
-            idcg = sum(1.0 / math.log2(r + 2) for r in range(ideal))
-            vals.append(dcg / idcg if idcg > 0 else 0.0)
-        metrics[f"NDCG@{k}_V2T"] = float(torch.tensor(vals).mean().item())
-    return metrics
+    ranks = gt_ranks(similarity_matrix, gt_sets)
+    sizes = [len(s) for s in gt_sets]
+    return {f"NDCG@{k}_V2T": float(torch.tensor(ndcg_from_ranks(ranks, sizes, min(k, n_c))).mean().item()) for k in k_values}
 
 
 def compute_median_rank(similarity_matrix: torch.Tensor, global_gt_indices) -> int:
@@ -145,8 +161,8 @@ def compute_median_rank(similarity_matrix: torch.Tensor, global_gt_indices) -> i
     if n_q == 0:
         return 0
     gt_sets = _normalize_ground_truth_sets(global_gt_indices, n_q)
-    ranks = [r if r is not None else n_c for r in _best_ranks(_order(similarity_matrix), gt_sets, n_c)]
-    return int(torch.tensor(ranks, dtype=torch.float).median().item())
+    best = [r[0] if r else n_c for r in gt_ranks(similarity_matrix, gt_sets)]
+    return int(torch.tensor(best, dtype=torch.float).median().item())
 
 
 def compute_map(similarity_matrix: torch.Tensor, global_gt_indices) -> float:
@@ -154,14 +170,4 @@ def compute_map(similarity_matrix: torch.Tensor, global_gt_indices) -> float:
     if n_q == 0:
         return 0.0
     gt_sets = _normalize_ground_truth_sets(global_gt_indices, n_q)
-    order = _order(similarity_matrix)
-    aps = []
-    for i, s in enumerate(gt_sets):
-        hits, ps = 0, 0.0
-        if s:
-            for rank, j in enumerate(order[i], start=1):
-                if int(j) in s:
-                    hits += 1
-                    ps += hits / rank
-        aps.append(ps / hits if hits else 0.0)
-    return float(torch.tensor(aps).mean().item())
+    return float(torch.tensor(ap_from_ranks(gt_ranks(similarity_matrix, gt_sets))).mean().item())

@@ -172,6 +172,11 @@ int dcc_clip_coef(const double* sumsq, float max_norm, float* coef, float* norm_
 int dcc_scale_grads(const void* tab, const void* work, int nblocks, const float* coef, void* stream);
 int dcc_adam_step(const void* tab, const void* work, int nblocks, const float* grad_scale, void* stream);
 
+/* ---- epoch-end retrieval ranks (csrc/misc.hip): position of each ground-truth candidate in the stable descending order
+ * of its similarity row — all of utils/retrieval_metrics.py:65-324 (Recall@k, MRR, MAP, NDCG@k, median rank) follows from
+ * these integers.  gt int32 [Nq, G], -1 = empty; ranks int32 [Nq, G], 1-based, 0 for empty slots. */
+int dcc_retrieval_ranks(const float* sim, int64_t ld, const int* gt, int* ranks, int Nq, int Nc, int G, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

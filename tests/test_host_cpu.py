@@ -125,21 +125,38 @@ def test_runner_validates_config():
         r.validate()
 
 
+def _stable_ranks(sim, gt_sets):
+    """1-based positions of the ground-truth candidates in a stable descending argsort (what the GPU kernel returns)."""
+    import numpy as np
+
+    order = np.argsort(-np.asarray(sim, dtype=np.float64), axis=1, kind="stable")
+    out = []
+    for i, s in enumerate(gt_sets):
+        inv = np.empty(order.shape[1], dtype=np.int64)
+        inv[order[i]] = np.arange(order.shape[1])
+        out.append(sorted(int(inv[j]) + 1 for j in s if 0 <= j < order.shape[1]))
+    return out
+
+
 def test_retrieval_metrics_host_part_matches_golden():
+    """The host half of the retrieval metrics (arithmetic on ground-truth ranks) against values produced by the
+    reference's utils/retrieval_metrics.py; the ranks themselves come from the GPU kernel (tests/test_retrieval_gpu.py)."""
     import numpy as np
 
     from deepcoro_clip_amd import retrieval_metrics as RM
 
     g = np.load(os.path.join(ROOT, "tests", "golden", "retrieval.npz"))
-    sim, gt = torch.from_numpy(g["sim"]), torch.arange(100)
-    rec = RM.compute_recall_at_k(sim, gt, [1, 5, 10])
-    assert [rec["Recall@1"], rec["Recall@5"], rec["Recall@10"]] == pytest.approx(list(g["recall"]))
-    assert RM.compute_mrr(sim, gt)["MRR_V2T"] == pytest.approx(float(g["mrr"]), abs=1e-9)
-    assert RM.compute_map(sim, gt) == pytest.approx(float(g["map"]), abs=1e-7)
-    assert RM.compute_median_rank(sim, gt) == int(g["median"])
-    assert RM.compute_ndcg_at_k(sim, gt, [5, 10])["NDCG@5_V2T"] == pytest.approx(float(g["ndcg"][0]), abs=1e-7)
-    gt2 = [[int(x) for x in row if x >= 0] for row in g["gt2"]]
-    sim2 = torch.from_numpy(g["sim2"])
-    assert RM.compute_median_rank(sim2, gt2) == int(g["median2"])
-    assert RM.compute_map(sim2, gt2) == pytest.approx(float(g["map2"]), abs=1e-7)
-    assert RM.compute_recall_at_k(sim2, gt2, [10])["Recall@10"] == pytest.approx(float(g["recall2"][2]))
+    r = _stable_ranks(g["sim"], [{i} for i in range(100)])
+    assert [RM.recall_from_ranks(r, k) for k in (1, 5, 10)] == pytest.approx(list(g["recall"]))
+    assert RM.mrr_from_ranks(r) == pytest.approx(float(g["mrr"]), abs=1e-9)
+    assert float(np.mean(RM.ap_from_ranks(r))) == pytest.approx(float(g["map"]), abs=1e-7)
+    assert float(np.mean(RM.ndcg_from_ranks(r, [1] * 100, 5))) == pytest.approx(float(g["ndcg"][0]), abs=1e-7)
+    assert float(np.mean(RM.ndcg_from_ranks(r, [1] * 100, 10))) == pytest.approx(float(g["ndcg"][1]), abs=1e-7)
+    gt2 = [{int(x) for x in row if x >= 0} for row in g["gt2"]]
+    r2 = _stable_ranks(g["sim2"], gt2)
+    assert float(np.mean(RM.ap_from_ranks(r2))) == pytest.approx(float(g["map2"]), abs=1e-7)
+    assert RM.mrr_from_ranks(r2) == pytest.approx(float(g["mrr2"]), abs=1e-9)
+    assert float(np.mean(RM.ndcg_from_ranks(r2, [len(x) for x in gt2], 3))) == pytest.approx(float(g["ndcg2"][0]), abs=1e-7)
+    assert [RM.recall_from_ranks(r2, k) for k in (1, 3, 5)] == pytest.approx(list(g["recall2"]))
+    with pytest.raises(Exception):  # the full functions need the GPU rank kernel: no CPU path
+        RM.compute_recall_at_k(torch.from_numpy(g["sim"]), torch.arange(100), [1])
