@@ -86,6 +86,22 @@ __global__ void scale_rows_kernel(const T* __restrict__ x, const float* __restri
   }
 }
 
+// uint8 frames -> normalised fp32: (x - mean[c]) / std[c] with the channel innermost (torchvision v2.Normalize as
+// used by utils/video.py:278-288, applied on the GPU so that the host ships 1 byte per sample instead of 4)
+__global__ void u8_normalize_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t n4, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ stdv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t v = reinterpret_cast<const uint32_t*>(src)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = (int)((i * 4 + e) % C);
+      o[e] = __fdiv_rn(__fsub_rn((float)((v >> (8 * e)) & 0xffu), mean[c]), stdv[c]);
+    }
+    reinterpret_cast<f32x4*>(dst)[i] = o;
+  }
+}
+
 // out = dy * gelu'(pre)
 template <typename T>
 __global__ void dgelu_mul_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ out, int64_t n) {
@@ -344,6 +360,13 @@ extern "C" int dcc_axpby(void* out, float a, const void* x, float b, const void*
   if (dtype == DCC_BF16) hipLaunchKernelGGL((axpby_kernel<bf16_t>), g, dim3(256), 0, ST, (bf16_t*)out, a, (const bf16_t*)x, b, (const bf16_t*)y, n);
   else if (dtype == DCC_F32) hipLaunchKernelGGL((axpby_kernel<float>), g, dim3(256), 0, ST, (float*)out, a, (const float*)x, b, (const float*)y, n);
   else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+extern "C" int dcc_u8_normalize(const uint8_t* src, float* dst, int64_t n, int C, const float* mean, const float* stdv, void* stream) {
+  if (!src || !dst || !mean || !stdv || n <= 0 || C <= 0 || (n % 4) || ((uintptr_t)src & 3) || ((uintptr_t)dst & 15)) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(n / 4, 2));
+  hipLaunchKernelGGL(u8_normalize_kernel, g, dim3(256), 0, ST, src, dst, n / 4, C, mean, stdv);
   return dcc_check_launch();
 }
 

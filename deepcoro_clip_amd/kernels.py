@@ -162,23 +162,20 @@ def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=N
     return out
 
 
-_NICE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 128)
-
-
 def wgrad_splitk(rows: int, n: int, k: int) -> int:
     """Split factor for weight-gradient GEMMs (reduction over `rows`, output n x k).
 
-    Measured on MI355X (scratch/wgrad_sweep.py) with the persistent ring kernel: one work item (128x128 output tile x
+    Measured on MI355X (scratch/wgrad_sweep*.py) with the persistent ring kernel: one work item (128x128 output tile x
     K split) per CU is the sweet spot — fewer leave CUs idle, more only add fp32 atomics (served at the memory side).
-    So: the largest "nice" split with tiles x split <= 256 CUs; outputs with more than 128 tiles still take a split of 2
-    when the reduction is long, which evens out the second round of items."""
+    So: the largest split with tiles x split <= 256 CUs; outputs with more tiles than half the CUs pick the split
+    (<= 4) that wastes least of the last round of items."""
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
     ksteps = (rows + 63) // 64
     if tiles > 128:
-        want = 2 if ksteps >= 64 else 1
+        want = min(range(1, 5), key=lambda s: -(-tiles * s // 256) / s + 0.02 * s) if ksteps >= 64 else 1
     else:
-        want = max(s for s in _NICE_SPLITS if s * tiles <= 256)
-    return int(max(1, min(want, ksteps // 4)))
+        want = max(1, 256 // tiles)
+    return int(max(1, min(want, ksteps // 4, 128)))
 
 
 # ------------------------------------------------------------------------------------ attention
@@ -411,6 +408,17 @@ def axpby(x: torch.Tensor, y: torch.Tensor | None = None, a: float = 1.0, b: flo
     if out is None:
         out = torch.empty_like(x)
     L.call("dcc_axpby", L.ptr(out), float(a), L.ptr(x), float(b), L.ptr(y), x.numel(), L.dt(x), L.stream())
+    return out
+
+
+def u8_normalize(frames: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
+    """uint8 [..., C] frames -> fp32 (x - mean[c]) / std[c]."""
+    L.require_cuda(frames, mean, std)
+    assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.numel() % 4 == 0
+    C = frames.shape[-1]
+    assert mean.dtype == std.dtype == torch.float32 and mean.numel() == C and std.numel() == C
+    out = torch.empty(frames.shape, device=frames.device, dtype=torch.float32)
+    L.call("dcc_u8_normalize", L.ptr(frames), L.ptr(out), frames.numel(), C, L.ptr(mean), L.ptr(std), L.stream())
     return out
 
 

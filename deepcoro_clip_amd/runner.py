@@ -100,7 +100,17 @@ class VideoContrastiveLearningRunner:
 
     def _preprocess_inputs(self, batch: dict):
         videos = batch["videos"].to(self.device, non_blocking=True)
-        if videos.dtype != torch.float32:
+        if videos.dtype == torch.uint8:
+            # optional fast input path: raw uint8 frames, normalised on the GPU exactly like
+            # utils/video.py:278-288 does on the host ((x - mean) / std per channel); 4x less H2D traffic
+            mean, std = _cfg(self.config, "video_mean", None), _cfg(self.config, "video_std", None)
+            if mean is None or std is None:
+                raise ValueError("uint8 videos need config.video_mean / config.video_std (per-channel, pixel units)")
+            C = videos.shape[-1]
+            as_vec = lambda v: torch.tensor([float(v)] * C if isinstance(v, (int, float)) else [float(x) for x in v][:C],  # noqa: E731
+                                            dtype=torch.float32, device=videos.device)
+            videos = K.u8_normalize(videos.contiguous(), as_vec(mean), as_vec(std))
+        elif videos.dtype != torch.float32:
             videos = K.cast(videos.contiguous(), torch.float32)
         videos = K.nan_to_num_(videos.contiguous(), 0.0, 0.0, 0.0)
         step_inputs: Dict[str, Any] = {"videos": videos}

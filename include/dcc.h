@@ -120,6 +120,9 @@ int dcc_cast2d(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t ro
                int dst_dtype, void* stream);
 int dcc_axpby(void* out, float a, const void* x, float b, const void* y, int64_t n, int dtype, void* stream);
 int dcc_dgelu_mul(const void* dy, const void* pre, void* out, int64_t n, int dtype, void* stream);
+/* uint8 frames -> (x - mean[c]) / std[c] fp32, channel innermost (v2.Normalize of utils/video.py:278-288 moved to the GPU:
+ * the host uploads 1 byte per sample).  n = number of samples (multiple of 4), mean/std device fp32 [C]. */
+int dcc_u8_normalize(const uint8_t* src, float* dst, int64_t n, int C, const float* mean, const float* stdv, void* stream);
 /* torchvision.ops.StochasticDepth(p, "row") of MultiscaleBlock (torchvision mvit.py via models/video_encoder.py:93):
  * out = resid + x * scale[sample] with scale = bernoulli(1-p)/(1-p) per clip; resid may be null (backward). */
 int dcc_scale_rows(const void* x, const float* scale, const void* resid, void* out, int64_t samples,

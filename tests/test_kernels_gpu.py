@@ -259,3 +259,15 @@ def test_layernorm_skip_sums_both_gradients(dtype, tol):
     xr2 = x0.clone().requires_grad_(True)
     F.layer_norm(xr2, (C,), gam0, bet0, 1e-6).backward(d1)
     assert _rel(x2.grad.float(), xr2.grad) < tol
+
+
+def test_u8_normalize_matches_host_normalisation_bit_exact():
+    """uint8 frames normalised on the GPU == float(x).sub(mean).div(std) of utils/video.py (v2.Normalize), bit for bit."""
+    from deepcoro_clip_amd import kernels as K
+
+    g = _gen(17)
+    frames = torch.randint(0, 256, (2, 3, 20, 28, 3), generator=g, dtype=torch.uint8)
+    mean, std = torch.tensor([104.5, 99.25, 97.0]), torch.tensor([53.1, 51.7, 50.9])
+    ref = (frames.float() - mean) / std
+    out = K.u8_normalize(frames.cuda(), mean.cuda(), std.cuda())
+    assert out.dtype == torch.float32 and torch.equal(out.cpu(), ref)
