@@ -32,10 +32,18 @@ def _needs(obj: Path, deps: list[Path]) -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
+# per-file code-generation options
+FILE_FLAGS = {
+    # softmax runs on the MFMA results: with AGPR accumulators hipcc copies every score AGPR->VGPR->AGPR (a third of
+    # the kernels' VALU instructions); VGPR-form MFMA removes the copies at the price of occupancy (measured faster)
+    "attention.hip": [*os.environ.get("DCC_ATTN_FLAGS", "-mllvm -amdgpu-mfma-vgpr-form").split()],
+}
+
+
 def _compile(src: Path, headers: list[Path], force: bool) -> Path:
     obj = OBJ_DIR / (src.stem + ".o")
     if force or _needs(obj, [src] + headers):
-        cmd = [HIPCC, *CFLAGS, "-I", str(CSRC), "-c", str(src), "-o", str(obj)]
+        cmd = [HIPCC, *CFLAGS, *FILE_FLAGS.get(src.name, []), "-I", str(CSRC), "-c", str(src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
