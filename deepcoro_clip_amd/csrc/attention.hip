@@ -55,8 +55,16 @@ template <typename T, int D> struct TileRegs {
   vec16_t<T> v[NCH];
 };
 
+// Rows come through a buffer descriptor whose range ends with the last valid row: rows past n_valid read as zero
+// without a branch (branchy loads keep hipcc from hoisting them and cost 64-bit address arithmetic per chunk).
 template <typename T, int D>
-__device__ __forceinline__ void tile_load(TileRegs<T, D>& r, const T* base, int64_t row_stride, int row0, int n_valid,
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const T* base, int64_t row_stride, int n_valid) {
+  const int64_t bytes = n_valid > 0 ? ((int64_t)(n_valid - 1) * row_stride + D) * (int64_t)sizeof(T) : 0;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, bytes > 0x7fffffffLL ? 0x7fffffff : (int)bytes, 0x00020000);
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void tile_load(TileRegs<T, D>& r, __amdgpu_buffer_rsrc_t rsrc, int row_stride_bytes, int row0,
                                           int tid) {
   using RT = RowTile<T, D>;
   using V = vec16_t<T>;
@@ -64,11 +72,7 @@ __device__ __forceinline__ void tile_load(TileRegs<T, D>& r, const T* base, int6
   for (int i = 0; i < TileRegs<T, D>::NCH; ++i) {
     const int id = tid + ANT * i;
     const int rr = id / RT::CPR, c = id % RT::CPR;
-    V v;
-#pragma unroll
-    for (int e = 0; e < RT::CH; ++e) v[e] = (T)0.0f;
-    if (row0 + rr < n_valid) v = *reinterpret_cast<const V*>(base + (int64_t)(row0 + rr) * row_stride + c * RT::CH);
-    r.v[i] = v;
+    r.v[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (row0 + rr) * row_stride_bytes + c * 16, 0, 0));
   }
 }
 
@@ -211,10 +215,11 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(AttnParams p) {
 
   TileRegs<T, DQK> rk;
   TileRegs<T, DV> rv;
+  const __amdgpu_buffer_rsrc_t rsK = tile_rsrc<T, DQK>(K, p.skn, p.Nk), rsV = tile_rsrc<T, DV>(V, p.svn, p.Nk);
   float rbias = -INFINITY;
   auto prefetch = [&](int kt0) {
-    tile_load<T, DQK>(rk, K, p.skn, kt0, p.Nk, tid);
-    tile_load<T, DV>(rv, V, p.svn, kt0, p.Nk, tid);
+    tile_load<T, DQK>(rk, rsK, (int)p.skn * (int)sizeof(T), kt0, tid);
+    tile_load<T, DV>(rv, rsV, (int)p.svn * (int)sizeof(T), kt0, tid);
     if (tid < TK) {
       const int key = kt0 + tid;
       rbias = -INFINITY;
@@ -322,10 +327,11 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
 
   TileRegs<T, DQK> rk;
   TileRegs<T, DV> rv;
+  const __amdgpu_buffer_rsrc_t rsK = tile_rsrc<T, DQK>(K, p.skn, p.Nk), rsV = tile_rsrc<T, DV>(V, p.svn, p.Nk);
   float rbias = -INFINITY;
   auto prefetch = [&](int kt0) {
-    tile_load<T, DQK>(rk, K, p.skn, kt0, p.Nk, tid);
-    tile_load<T, DV>(rv, V, p.svn, kt0, p.Nk, tid);
+    tile_load<T, DQK>(rk, rsK, (int)p.skn * (int)sizeof(T), kt0, tid);
+    tile_load<T, DV>(rv, rsV, (int)p.svn * (int)sizeof(T), kt0, tid);
     if (tid < TK) {
       const int key = kt0 + tid;
       rbias = -INFINITY;
@@ -350,10 +356,16 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
       for (int s = 0; s < DQK / 16; ++s) S = mma16(row_frag<T, DQK>(ldsK, 32 * sub, s, lane), qf[s], S);
 #pragma unroll
       for (int s = 0; s < DV / 16; ++s) dP = mma16(row_frag<T, DV>(ldsV, 32 * sub, s, lane), dof[s], dP);
+      const bool plain = !p.kbias && (kt0 + 32 * sub + 32 <= p.Nk);  // no key bias, no tail: skip the bias reads
+      if (plain) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pr = fast_exp2(S[e] * scale2 + ldsB[32 * sub + acc_row(e, h)] - lse2);
-        S[e] = pr * (dP[e] - dv);  // dz^T
+        for (int e = 0; e < 16; ++e) S[e] = fast_exp2(S[e] * scale2 - lse2) * (dP[e] - dv);  // dz^T
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pr = fast_exp2(S[e] * scale2 + ldsB[32 * sub + acc_row(e, h)] - lse2);
+          S[e] = pr * (dP[e] - dv);  // dz^T
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -428,10 +440,11 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
 
   TileRegs<T, DQK> rq;
   TileRegs<T, DV> ro;
+  const __amdgpu_buffer_rsrc_t rsQ = tile_rsrc<T, DQK>(Q, p.sqn, p.Nq), rsO = tile_rsrc<T, DV>(dO, p.son, p.Nq);
   float rl = INFINITY, rd = 0.0f;
   auto prefetch = [&](int qq0) {
-    tile_load<T, DQK>(rq, Q, p.sqn, qq0, p.Nq, tid);
-    tile_load<T, DV>(ro, dO, p.son, qq0, p.Nq, tid);
+    tile_load<T, DQK>(rq, rsQ, (int)p.sqn * (int)sizeof(T), qq0, tid);
+    tile_load<T, DV>(ro, rsO, (int)p.son * (int)sizeof(T), qq0, tid);
     if (tid < TK) {
       const int q = qq0 + tid;
       rl = (q < p.Nq) ? LSE[q] * LOG2E : INFINITY;
