@@ -90,7 +90,9 @@ def ptr(t):
 
 
 def stream() -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw hipStream_t of torch's current stream (the C getters: `torch.cuda.current_stream()` builds a Stream object
+    and resolves the device through several Python layers, ~9 us x several hundred launches per step on the host)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def require_cuda(*tensors) -> None:

@@ -335,7 +335,7 @@ def dwconv_bwd_weight(dy: torch.Tensor, x: torch.Tensor, g: PoolGeom, dw: torch.
     L.require_cuda(dy, x, dw)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
     n = 1024 * g.C * g.kernel[0] * g.kernel[1] * g.kernel[2]  # DCC_DWCONV_WS_BLOCKS x taps x C
-    key = (str(dy.device), n, torch.cuda.current_stream(dy.device).cuda_stream)  # one scratch buffer per stream: the
+    key = (dy.device.index, n, L.stream().value)  # one scratch buffer per stream: the
     ws = _DWCONV_WS.get(key)                                                      # q/k/v branches run concurrently
     if ws is None:
         ws = _DWCONV_WS[key] = torch.empty(n, device=dy.device, dtype=torch.float32)
