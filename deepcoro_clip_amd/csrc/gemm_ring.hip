@@ -152,6 +152,13 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
       if (L.idx >= geo.items) return;
       char* st = smem + (loads_issued % NS) * STAGE_B;
       const int kb = L.ks0 + l_kt;
+#ifdef DCC_RING_PROFILE
+      if (p.flags & 0x1000) {  // experiment: no DMA at all (results are garbage) — isolates LDS write contention
+        ++loads_issued;
+        if (++l_kt == L.nk) { L = locate(L.idx + G); l_kt = 0; bind_loads(); }
+        return;
+      }
+#endif
       // the K offset goes into the VGPR offset: the descriptor's range check does not see the scalar offset
       const int soA = kb * kstrideA, soB = kb * kstrideB;
       // a k-contiguous operand's K tail (K % 64 != 0) would run into the next row: those chunks are sent out of range
