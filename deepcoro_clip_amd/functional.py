@@ -393,10 +393,45 @@ class MvitAttnCoreFn(torch.autograd.Function):
         scale = cfg["scale"]
         dO4 = _c(dO).view(B, Nq, H, D)
         dQf, dKf, dVn = K.attn_bwd(Qf, Kf, Vn, O, dO4, lse, scale=scale, residual=ctx.residual, res_start=1)
-        # queries: dQf[:, :D] already holds attention path + residual shortcut; the table path goes through
-        # dP (scatter of the augmentation columns), then two GEMMs: d tables = dP^T q, dq = dP Rcat + dQf[:, :D]
         f32 = dict(device=dev, dtype=torch.float32)
         lens, Lp = ctx.lens, ctx.Lp
+        rope = cfg.get("rope")
+        dqkv = torch.empty((B, N, 3, H, D), device=dev, dtype=dt)
+        grads = {}
+        small = zeros_f32((3, 2, D), dev)  # LayerNorm gamma/beta gradients of the q, k, v pools
+        small_w = zeros_f32((3, D, 27), dev)
+        qkv5 = qkv.view(B, N, 3, H, D)
+
+        def pool_branch(name, i, dy4, conv, mean, rstd, gam, w):
+            """LayerNorm backward -> pool data gradient + pool weight gradient of one of the q / k / v branches."""
+            g = geo[name]
+            rows = B * g.n_out * H
+            if dy4.is_contiguous():
+                dy2 = dy4.view(rows, D)
+            else:  # dk is a column slice of the [.., DQK] buffer: rows are strided by DQK
+                dy2 = dy4.as_strided((rows, D), (dy4.stride(2), 1), dy4.storage_offset())
+            dgam, dbet = small[i, 0], small[i, 1]
+            dw = small_w[i]
+            dconv = K.layernorm_bwd(dy2, conv.view(rows, D), mean, rstd, gam, dgam, dbet)
+            dconv4 = dconv.view(B, g.n_out, H, D)
+            K.pool_bwd_data(dconv4, dqkv[:, :, i], g, w.reshape(D, 27))
+            K.dwconv_bwd_weight(dconv4, qkv5[:, :, i], g, dw)
+            grads[name] = (dw.view(D, 1, 3, 3, 3), dgam, dbet)
+
+        # the k and v branches only need dKf / dVn: they start on their own streams right away, underneath the
+        # query side's rel-pos scatter and its two GEMMs
+        br = _Branches(dev)
+        with br.stream(1):
+            dk = dKf[..., :D]  # the one-hot columns are constants
+            if rope is not None:
+                dk_d = torch.empty((B, Nk, H, D), device=dev, dtype=dKf.dtype)
+                K.rope(dk, dk_d, rope["cos_k"], rope["sin_k"], backward=True)
+                dk = dk_d
+            pool_branch("k", 1, dk, ck, mk, rk, gk, wk)
+        with br.stream(2):
+            pool_branch("v", 2, dVn, cv, mv, rv, gv, wv)
+        # queries: dQf[:, :D] already holds attention path + residual shortcut; the table path goes through
+        # dP (scatter of the augmentation columns), then two GEMMs: d tables = dP^T q, dq = dP Rcat + dQf[:, :D]
         dims_q = K.relpos_dims(B, H, D, A, Lp, geo["q"].out_thw, geo["k"].out_thw, lens)
         rows_q = B * Nq * H
         dP = torch.empty((rows_q, Lp), device=dev, dtype=dt)
@@ -406,34 +441,9 @@ class MvitAttnCoreFn(torch.autograd.Function):
         drel = (drel_cat[:lens[0]], drel_cat[lens[0]:lens[0] + lens[1]], drel_cat[lens[0] + lens[1]:sum(lens)])
         dq = K.gemm(dP, Rcat, b_km=True, resid=dQf.view(-1, DQK)[:, :D]).view(B, Nq, H, D)
         del dP
-        dk = dKf[..., :D]  # the one-hot columns are constants
-        rope = cfg.get("rope")
         if rope is not None:
             K.rope(dq, dq, rope["cos_q"], rope["sin_q"], backward=True)
-            dk_d = torch.empty((B, Nk, H, D), device=dev, dtype=dKf.dtype)
-            K.rope(dk, dk_d, rope["cos_k"], rope["sin_k"], backward=True)
-            dk = dk_d
-        dqkv = torch.empty((B, N, 3, H, D), device=dev, dtype=dt)
-        grads = {}
-        small = zeros_f32((3, 2, D), dev)  # LayerNorm gamma/beta gradients of the q, k, v pools
-        small_w = zeros_f32((3, D, 27), dev)
-        br = _Branches(dev)
-        for name, i, dy4, conv, mean, rstd, gam, w in (("q", 0, dq, cq, mq, rq, gq, wq), ("k", 1, dk, ck, mk, rk, gk, wk),
-                                                         ("v", 2, dVn, cv, mv, rv, gv, wv)):
-            g = geo[name]
-            rows = B * g.n_out * H
-            if dy4.is_contiguous():
-                dy2 = dy4.view(rows, D)
-            else:  # dk is a column slice of the [.., DQK] buffer: rows are strided by DQK
-                dy2 = dy4.as_strided((rows, D), (dy4.stride(2), 1), dy4.storage_offset())
-            dgam, dbet = small[i, 0], small[i, 1]
-            dw = small_w[i]
-            with br.stream(i):  # LayerNorm backward -> pool data gradient + pool weight gradient, one stream per branch
-                dconv = K.layernorm_bwd(dy2, conv.view(rows, D), mean, rstd, gam, dgam, dbet)
-                dconv4 = dconv.view(B, g.n_out, H, D)
-                K.pool_bwd_data(dconv4, dqkv[:, :, i], g, w.reshape(D, 27))
-                K.dwconv_bwd_weight(dconv4, qkv.view(B, N, 3, H, D)[:, :, i], g, dw)
-            grads[name] = (dw.view(D, 1, 3, 3, 3), dgam, dbet)
+        pool_branch("q", 0, dq, cq, mq, rq, gq, wq)
         br.join()
         return (dqkv.view(B * N, 3 * H * D), grads["q"][0], grads["k"][0], grads["v"][0], grads["q"][1], grads["q"][2],
                 grads["k"][1], grads["k"][2], grads["v"][1], grads["v"][2], drel[0], drel[1], drel[2], None)
