@@ -338,7 +338,19 @@ struct RunGeom {
   PoolGeom g;
   int runsW, runs, cpr, slots;
   FastDiv d_cpr, d_runsW, d_Ho, d_To, d_H, d_Ws, d_Hs, d_T;
+  // buffer addressing of the stencil input ("x" side) and of dy ("y" side): spans and strides in BYTES (32-bit)
+  unsigned xspan, bxb, bxn, bxh;
+  unsigned yspan, byb, byn, byh;
 };
+
+// Stencil inputs are read with raw buffer loads: a lane whose tap falls into the zero padding gets an offset >= the
+// buffer size and the hardware returns zeros, so no per-element select and no address clamp is needed (the selects
+// and 64-bit address arithmetic were 2/3 of the instruction stream of the first version).
+constexpr unsigned OOB = 0xF0000000u;   // offsets are combined with a saturating add: OOB + anything stays out of range
+__device__ __forceinline__ unsigned sat_add(unsigned a, unsigned b) { return __builtin_elementwise_add_sat(a, b); }
+template <typename TD> __device__ __forceinline__ __amdgpu_buffer_rsrc_t span_rsrc(const TD* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<TD*>(p), 0, (int)bytes, 0x00020000);
+}
 
 // raw (unconverted) CV-element vector: issue all loads of a phase first, convert when consumed
 template <typename TD, int CV> struct RawCV { f32x4 q[sizeof(TD) * CV / 16]; };
@@ -346,6 +358,13 @@ template <typename TD, int CV> __device__ __forceinline__ RawCV<TD, CV> load_raw
   RawCV<TD, CV> r;
 #pragma unroll
   for (int i = 0; i < (int)(sizeof(TD) * CV / 16); ++i) r.q[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p) + 16 * i);
+  return r;
+}
+template <typename TD, int CV> __device__ __forceinline__ RawCV<TD, CV> load_raw_buf(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  RawCV<TD, CV> r;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(TD) * CV / 16); ++i)  // the 16*i goes into soffset, which the range check ignores
+    r.q[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 16 * i, 0));
   return r;
 }
 template <typename TD, int CV> __device__ __forceinline__ void raw_to_f32(const RawCV<TD, CV>& r, float* f) {
@@ -429,42 +448,36 @@ __global__ __launch_bounds__(256) void dw3_run_kernel(const TD* __restrict__ x, 
     return;
   }
   const RunPos p = run_pos(run, r, WT);
-  const TD* xb = x + p.b * g.sxb + p.hd * g.sxh + c * CV;
+  const __amdgpu_buffer_rsrc_t rsx = span_rsrc(x, r.xspan);
+  const unsigned xbase = p.b * r.bxb + p.hd * r.bxh + c * (CV * (unsigned)sizeof(TD));
   T* yb = y + p.b * g.syb + p.hd * g.syh + c * CV;
   float acc[WT][CV];
 #pragma unroll
   for (int i = 0; i < WT; ++i)
 #pragma unroll
     for (int e = 0; e < CV; ++e) acc[i][e] = 0.0f;
-  // Branch-free: coordinates are clamped for the address and the tap weight is zeroed instead, so that all loads of a
-  // temporal slab (3 rows x SEG columns) are in flight together — the kernel is bound by memory latency, not by
-  // instruction count.
+  // All loads of a temporal slab (3 rows x SEG columns) are in flight together; padding taps read zeros (OOB offset).
   const int col0 = p.w0 * S - 1;
-  int coff[SEG];
-  bool cok[SEG];
+  unsigned coff[SEG];
 #pragma unroll
   for (int j = 0; j < SEG; ++j) {
     const int col = col0 + j;
-    cok[j] = col >= 0 && col < g.Ws;
-    coff[j] = col < 0 ? 0 : (col >= g.Ws ? g.Ws - 1 : col);
+    coff[j] = (col >= 0 && col < g.Ws) ? (unsigned)col * r.bxn : OOB;
   }
 #pragma unroll 1
   for (int kt = 0; kt < 3; ++kt) {  // rolled: one slab of loads in flight is what the register file holds
     const int t = p.to + kt - 1;
     const bool tok = t >= 0 && t < g.T;
-    const int tc = t < 0 ? 0 : (t >= g.T ? g.T - 1 : t);
     RawCV<TD, CV> raw[3][SEG];
-    bool rok[3];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int hh = p.ho * S + kh - 1;
-      rok[kh] = tok && hh >= 0 && hh < g.Hs;
-      const int hc = hh < 0 ? 0 : (hh >= g.Hs ? g.Hs - 1 : hh);
-      const TD* row = xb + (int64_t)(g.has_cls + (tc * g.Hs + hc) * g.Ws) * g.sxn;
+      const bool ok = tok && hh >= 0 && hh < g.Hs;
+      const unsigned row = ok ? xbase + (unsigned)(g.has_cls + (t * g.Hs + hh) * g.Ws) * r.bxn : OOB;
 #pragma unroll
       for (int j = 0; j < SEG; ++j) {
         if (S > 2 && (j % S) > 2) continue;  // columns between the windows of a wide stride are never used
-        raw[kh][j] = load_raw<TD, CV>(row + (int64_t)coff[j] * g.sxn);
+        raw[kh][j] = load_raw_buf<TD, CV>(rsx, sat_add(row, coff[j]));
       }
     }
 #pragma unroll
@@ -476,8 +489,7 @@ __global__ __launch_bounds__(256) void dw3_run_kernel(const TD* __restrict__ x, 
 #pragma unroll
         for (int q = 0; q < CV / 4; ++q) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(wp + 4 * q);
-          wt[kw][4 * q] = rok[kh] ? v[0] : 0.0f; wt[kw][4 * q + 1] = rok[kh] ? v[1] : 0.0f;
-          wt[kw][4 * q + 2] = rok[kh] ? v[2] : 0.0f; wt[kw][4 * q + 3] = rok[kh] ? v[3] : 0.0f;
+          wt[kw][4 * q] = v[0]; wt[kw][4 * q + 1] = v[1]; wt[kw][4 * q + 2] = v[2]; wt[kw][4 * q + 3] = v[3];
         }
       }
 #pragma unroll
@@ -485,8 +497,6 @@ __global__ __launch_bounds__(256) void dw3_run_kernel(const TD* __restrict__ x, 
         if (S > 2 && (j % S) > 2) continue;
         float f[CV];
         raw_to_f32<TD, CV>(raw[kh][j], f);
-#pragma unroll
-        for (int e = 0; e < CV; ++e) f[e] = cok[j] ? f[e] : 0.0f;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           if ((j - kw) >= 0 && (j - kw) % S == 0 && (j - kw) / S < WT) {
@@ -579,6 +589,212 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_strided_kernel(const TD* __r
   store_cv<T, CV>(dx + b * g.sxb + (int64_t)(g.has_cls + (t * g.Hs + hh) * g.Ws + ww) * g.sxn + hd * g.sxh + c * CV, acc);
 }
 
+// data gradient of a stride-2 pool whose input grid is exactly twice the output grid (every MViT stage transition):
+// a thread owns one 16-byte channel chunk of ONE input row over a run of WQ column pairs.  An even row 2a is reached
+// from output row a through kh = 1 only; an odd row 2a+1 from rows a (kh = 2) and a+1 (kh = 0).  Within a row, input
+// column 2b takes dy[b] (kw = 1) and column 2b+1 takes dy[b] (kw = 2) and dy[b+1] (kw = 0), so the run needs WQ+1 dy
+// columns per (kt, output row): 1.7-3.4 loads per output chunk instead of 6.75, and runs are ordered parity-major so
+// that the "second output row" branch is wave-uniform.
+template <typename T, typename TD, int WQ>
+__global__ __launch_bounds__(256) void dw3_bwd_data_s2_kernel(const TD* __restrict__ dy, T* __restrict__ dx,
+                                                              const float* __restrict__ w, RunGeom r) {
+  constexpr int CV = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float wl3[];  // [27][C]
+  const PoolGeom& g = r.g;
+  for (int i = threadIdx.x; i < 27 * g.C; i += 256) {
+    const int k = i / g.C, c = i - k * g.C;
+    wl3[i] = w[c * 27 + k];
+  }
+  __syncthreads();
+  const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
+  const int c = threadIdx.x - rs * r.cpr;
+  if ((int)rs >= r.slots) return;
+  const unsigned run = blockIdx.x * r.slots + rs;
+  const int nruns = r.runs * 2;  // r.runs = B * H * To * Ho * runsW (one per output row run), two input rows each
+  if ((int)run >= nruns) {
+    const int i = run - nruns;
+    if (g.has_cls && i < g.B * g.H) {
+      const int b = i / g.H, hd = i - b * g.H;
+      float f[CV];
+      load_cv<TD, CV>(dy + b * g.syb + hd * g.syh + c * CV, f);
+      store_cv<T, CV>(dx + b * g.sxb + hd * g.sxh + c * CV, f);
+    }
+    return;
+  }
+  // run -> (b, head, t, parity, a, first column pair)
+  const unsigned t1 = fdiv(run, r.d_runsW);
+  const int q0 = (run - t1 * r.runsW) * WQ;
+  const unsigned t2 = fdiv(t1, r.d_Ho);
+  const int a = t1 - t2 * g.Ho;
+  const int par = t2 & 1;
+  const unsigned t3 = t2 >> 1;
+  const unsigned t4 = fdiv(t3, r.d_T);
+  const int t = t3 - t4 * g.T;
+  const unsigned t5 = fdiv(t4, r.d_H);
+  const int hd = t4 - t5 * g.H, b = t5;
+  const __amdgpu_buffer_rsrc_t rsy = span_rsrc(dy, r.yspan);
+  const unsigned ybase = b * r.byb + hd * r.byh + c * (CV * (unsigned)sizeof(TD));
+  unsigned coff[WQ + 1];
+#pragma unroll
+  for (int j = 0; j <= WQ; ++j) coff[j] = (q0 + j < g.Wo) ? (unsigned)(q0 + j) * r.byn : OOB;
+  float acc[2 * WQ][CV];
+#pragma unroll
+  for (int i = 0; i < 2 * WQ; ++i)
+#pragma unroll
+    for (int e = 0; e < CV; ++e) acc[i][e] = 0.0f;
+  // output rows feeding this input row: (ho, kh) = (a, par ? 2 : 1) and, for odd rows, (a + 1, 0)
+  const int nrow = par ? 2 : 1;
+#pragma unroll 1
+  for (int kt = 0; kt < 3; ++kt) {
+    const int to = t + 1 - kt;
+    const bool tok = to >= 0 && to < g.To;
+    RawCV<TD, CV> raw[2][WQ + 1];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      if (rr < nrow) {
+        const int ho = a + rr;
+        const unsigned row = (tok && ho < g.Ho) ? ybase + (unsigned)(g.has_cls + (to * g.Ho + ho) * g.Wo) * r.byn : OOB;
+#pragma unroll
+        for (int j = 0; j <= WQ; ++j) raw[rr][j] = load_raw_buf<TD, CV>(rsy, sat_add(row, coff[j]));
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      if (rr < nrow) {
+        const int kh = par ? (rr ? 0 : 2) : 1;
+        float wt[3][CV];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float* wp = wl3 + ((kt * 3 + kh) * 3 + kw) * g.C + c * CV;
+#pragma unroll
+          for (int q = 0; q < CV / 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+            wt[kw][4 * q] = v[0]; wt[kw][4 * q + 1] = v[1]; wt[kw][4 * q + 2] = v[2]; wt[kw][4 * q + 3] = v[3];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j <= WQ; ++j) {
+          float f[CV];
+          raw_to_f32<TD, CV>(raw[rr][j], f);
+          if (j < WQ) {
+#pragma unroll
+            for (int e = 0; e < CV; ++e) { acc[2 * j][e] += f[e] * wt[1][e]; acc[2 * j + 1][e] += f[e] * wt[2][e]; }
+          }
+          if (j >= 1) {
+#pragma unroll
+            for (int e = 0; e < CV; ++e) acc[2 * j - 1][e] += f[e] * wt[0][e];
+          }
+        }
+      }
+    }
+  }
+  T* xb = dx + b * g.sxb + hd * g.sxh + c * CV + (int64_t)(g.has_cls + (t * g.Hs + 2 * a + par) * g.Ws + 2 * q0) * g.sxn;
+#pragma unroll
+  for (int i = 0; i < 2 * WQ; ++i)
+    if (q0 + i / 2 < g.Wo) store_cv<T, CV>(xb + (int64_t)i * g.sxn, acc[i]);
+}
+
+// data gradient of a stride-4 / stride-8 pool: windows do not overlap, so an input position has at most one tap per
+// axis and S-3 of every S rows / columns are plain zeros.  A thread owns one input row over a run of WQ output
+// columns (S * WQ input columns): 3 dy loads (one per temporal tap) give the 3 non-zero columns of a group, the rest
+// of the row segment is zero-filled — the kernel is a streaming write of dx.
+template <typename T, typename TD, int S, int WQ>
+__global__ __launch_bounds__(256) void dw3_bwd_data_wide_kernel(const TD* __restrict__ dy, T* __restrict__ dx,
+                                                                const float* __restrict__ w, RunGeom r) {
+  static_assert(S >= 4 && (S & (S - 1)) == 0, "non-overlapping windows");
+  constexpr int CV = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float wl3[];  // [27][C]
+  const PoolGeom& g = r.g;
+  for (int i = threadIdx.x; i < 27 * g.C; i += 256) {
+    const int k = i / g.C, c = i - k * g.C;
+    wl3[i] = w[c * 27 + k];
+  }
+  __syncthreads();
+  const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
+  const int c = threadIdx.x - rs * r.cpr;
+  if ((int)rs >= r.slots) return;
+  const unsigned run = blockIdx.x * r.slots + rs;
+  const int nruns = g.B * g.H * g.T * g.Hs * r.runsW;
+  if ((int)run >= nruns) {
+    const int i = run - nruns;
+    if (g.has_cls && i < g.B * g.H) {
+      const int b = i / g.H, hd = i - b * g.H;
+      float f[CV];
+      load_cv<TD, CV>(dy + b * g.syb + hd * g.syh + c * CV, f);
+      store_cv<T, CV>(dx + b * g.sxb + hd * g.sxh + c * CV, f);
+    }
+    return;
+  }
+  const unsigned t1 = fdiv(run, r.d_runsW);
+  const int q0 = (run - t1 * r.runsW) * WQ;
+  const unsigned t2 = fdiv(t1, r.d_Hs);
+  const int h = t1 - t2 * g.Hs;
+  const unsigned t3 = fdiv(t2, r.d_T);
+  const int t = t2 - t3 * g.T;
+  const unsigned t4 = fdiv(t3, r.d_H);
+  const int hd = t3 - t4 * g.H, b = t4;
+  const int kh = (h + 1) & (S - 1), ho = (h + 1) / S;
+  const bool live = kh <= 2 && ho < g.Ho;
+  T* xrow = dx + b * g.sxb + hd * g.sxh + c * CV + (int64_t)(g.has_cls + (t * g.Hs + h) * g.Ws) * g.sxn;
+  float zero[CV];
+#pragma unroll
+  for (int e = 0; e < CV; ++e) zero[e] = 0.0f;
+  const bool last = q0 + WQ >= g.Wo;
+  if (!live) {  // a row no window touches
+    const int c0 = q0 == 0 ? 0 : S * q0 - 1, c1 = last ? g.Ws : S * (q0 + WQ) - 1;
+    for (int col = c0; col < c1; ++col) store_cv<T, CV>(xrow + (int64_t)col * g.sxn, zero);
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t rsy = span_rsrc(dy, r.yspan);
+  const unsigned ybase = b * r.byb + hd * r.byh + c * (CV * (unsigned)sizeof(TD)) + (unsigned)(g.has_cls + ho * g.Wo + q0) * r.byn;
+  RawCV<TD, CV> raw[3][WQ];
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+    const int to = t + 1 - kt;
+    const unsigned row = (to >= 0 && to < g.To) ? ybase + (unsigned)(to * g.Ho * g.Wo) * r.byn : OOB;
+#pragma unroll
+    for (int j = 0; j < WQ; ++j) raw[kt][j] = load_raw_buf<TD, CV>(rsy, sat_add(row, q0 + j < g.Wo ? j * r.byn : OOB));
+  }
+  float wt[3][3][CV];
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const float* wp = wl3 + ((kt * 3 + kh) * 3 + kw) * g.C + c * CV;
+#pragma unroll
+      for (int q = 0; q < CV / 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+        wt[kt][kw][4 * q] = v[0]; wt[kt][kw][4 * q + 1] = v[1]; wt[kt][kw][4 * q + 2] = v[2]; wt[kt][kw][4 * q + 3] = v[3];
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < WQ; ++j) {
+    if (q0 + j >= g.Wo) break;
+    float acc[3][CV];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int e = 0; e < CV; ++e) acc[kw][e] = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      float f[CV];
+      raw_to_f32<TD, CV>(raw[kt][j], f);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int e = 0; e < CV; ++e) acc[kw][e] += f[e] * wt[kt][kw][e];
+    }
+    const int cb = S * (q0 + j) - 1;  // column of tap kw = 0
+#pragma unroll
+    for (int kw = 0; kw < S; ++kw) {
+      const int col = cb + kw;
+      if (col >= 0 && col < g.Ws) store_cv<T, CV>(xrow + (int64_t)col * g.sxn, kw < 3 ? acc[kw < 3 ? kw : 0] : zero);
+    }
+  }
+  if (last)
+    for (int col = S * g.Wo - 1; col < g.Ws; ++col) store_cv<T, CV>(xrow + (int64_t)col * g.sxn, zero);
+}
+
 // skip-path max-pool data gradient: MaxPool3d k(1,3,3) s(1,2,2) p(0,1,1) with the argmax recorded by the forward
 // (tap = kh * 3 + kw).  One thread per input position chunk; the <= 2 x 2 windows that contain the position are
 // enumerated exactly (the generic kernel tests all 9 taps with 64-bit index arithmetic).
@@ -655,6 +871,7 @@ __global__ __launch_bounds__(256) void dw3_wgrad_kernel(const TD* __restrict__ d
   for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int e = 0; e < CV; ++e) acc[k][e] = 0.0f;
+  const __amdgpu_buffer_rsrc_t rsx = span_rsrc(x, r.xspan), rsy = span_rsrc(dy, r.yspan);
   if ((int)slot < slots3 * 3) {
     for (int it = 0; it < iters; ++it) {
       const unsigned run = (blockIdx.x * iters + it) * slots3 + rsl;
@@ -662,52 +879,38 @@ __global__ __launch_bounds__(256) void dw3_wgrad_kernel(const TD* __restrict__ d
       const RunPos p = run_pos(run, r, WT);
       const int t = p.to + kt - 1;
       const bool tok = t >= 0 && t < g.T;
-      const int tc = t < 0 ? 0 : (t >= g.T ? g.T - 1 : t);
-      // branch-free: every load of the run (WT dy chunks + 3 input row segments) is issued before the first FMA
+      // every load of the run (WT dy chunks + 3 input row segments) is issued before the first FMA; padding taps and
+      // columns past the end of a partial run read zeros through out-of-range buffer offsets
       RawCV<TD, CV> draw[WT];
-      const TD* dyb = dy + p.b * g.syb + p.hd * g.syh + c * CV + (int64_t)(g.has_cls + (p.to * g.Ho + p.ho) * g.Wo) * g.syn;
+      const unsigned ybase = p.b * r.byb + p.hd * r.byh + c * (CV * (unsigned)sizeof(TD)) +
+                             (unsigned)(g.has_cls + (p.to * g.Ho + p.ho) * g.Wo + p.w0) * r.byn;
 #pragma unroll
-      for (int i = 0; i < WT; ++i) {
-        const int wo = p.w0 + i < g.Wo ? p.w0 + i : g.Wo - 1;
-        draw[i] = load_raw<TD, CV>(dyb + (int64_t)wo * g.syn);
-      }
-      const T* xb = x + p.b * g.sxb + p.hd * g.sxh + c * CV;
+      for (int i = 0; i < WT; ++i) draw[i] = load_raw_buf<TD, CV>(rsy, p.w0 + i < g.Wo ? ybase + i * r.byn : OOB);
+      const unsigned xbase = p.b * r.bxb + p.hd * r.bxh + c * (CV * (unsigned)sizeof(T));
       const int col0 = p.w0 * S - 1;
       RawCV<T, CV> raw[3][SEG];
-      bool rok[3];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int hh = p.ho * S + kh - 1;
-        rok[kh] = tok && hh >= 0 && hh < g.Hs;
-        const int hc = hh < 0 ? 0 : (hh >= g.Hs ? g.Hs - 1 : hh);
-        const T* row = xb + (int64_t)(g.has_cls + (tc * g.Hs + hc) * g.Ws) * g.sxn;
+        const bool ok = tok && hh >= 0 && hh < g.Hs;
+        const unsigned row = ok ? xbase + (unsigned)(g.has_cls + (t * g.Hs + hh) * g.Ws) * r.bxn : OOB;
 #pragma unroll
         for (int j = 0; j < SEG; ++j) {
           if (S > 2 && (j % S) > 2) continue;
           const int col = col0 + j;
-          const int cc = col < 0 ? 0 : (col >= g.Ws ? g.Ws - 1 : col);
-          raw[kh][j] = load_raw<T, CV>(row + (int64_t)cc * g.sxn);
+          raw[kh][j] = load_raw_buf<T, CV>(rsx, sat_add(row, (col >= 0 && col < g.Ws) ? (unsigned)col * r.bxn : OOB));
         }
       }
       float dv[WT][CV];
 #pragma unroll
-      for (int i = 0; i < WT; ++i) {
-        raw_to_f32<TD, CV>(draw[i], dv[i]);
-        const bool ok = p.w0 + i < g.Wo;
-#pragma unroll
-        for (int e = 0; e < CV; ++e) dv[i][e] = ok ? dv[i][e] : 0.0f;
-      }
+      for (int i = 0; i < WT; ++i) raw_to_f32<TD, CV>(draw[i], dv[i]);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
         for (int j = 0; j < SEG; ++j) {
           if (S > 2 && (j % S) > 2) continue;
-          const int col = col0 + j;
-          const bool ok = rok[kh] && col >= 0 && col < g.Ws;
           float f[CV];
           raw_to_f32<T, CV>(raw[kh][j], f);
-#pragma unroll
-          for (int e = 0; e < CV; ++e) f[e] = ok ? f[e] : 0.0f;
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
             if ((j - kw) >= 0 && (j - kw) % S == 0 && (j - kw) / S < WT) {
@@ -745,7 +948,21 @@ RunGeom make_run_geom(const PoolGeom& g, int vec, int WT) {
   r.runs = g.B * g.H * g.To * g.Ho * r.runsW;
   r.d_cpr = mkdiv(r.cpr); r.d_runsW = mkdiv(r.runsW); r.d_Ho = mkdiv(g.Ho); r.d_To = mkdiv(g.To); r.d_H = mkdiv(g.H);
   r.d_Ws = mkdiv(g.Ws); r.d_Hs = mkdiv(g.Hs); r.d_T = mkdiv(g.T);
+  r.xspan = r.yspan = 0; r.bxb = r.bxn = r.bxh = r.byb = r.byn = r.byh = 0;
   return r;
+}
+
+// byte spans / strides for buffer addressing; esx / esy = element sizes of the tensors behind the x- and y-strides.
+// false when a tensor is too large for 32-bit offsets (callers then use the generic kernels).
+bool set_spans(RunGeom& r, int esx, int esy) {
+  const PoolGeom& g = r.g;
+  const int64_t nx = (int64_t)g.T * g.Hs * g.Ws + g.has_cls, ny = (int64_t)g.To * g.Ho * g.Wo + g.has_cls;
+  const int64_t xs = ((g.B - 1) * g.sxb + (nx - 1) * g.sxn + (g.H - 1) * g.sxh + g.C) * esx;
+  const int64_t ys = ((g.B - 1) * g.syb + (ny - 1) * g.syn + (g.H - 1) * g.syh + g.C) * esy;
+  if (xs >= 0x7fffffffLL || ys >= 0x7fffffffLL || g.sxb < 0 || g.sxn < 0 || g.sxh < 0 || g.syb < 0 || g.syn < 0 || g.syh < 0) return false;
+  r.xspan = (unsigned)xs; r.bxb = (unsigned)(g.sxb * esx); r.bxn = (unsigned)(g.sxn * esx); r.bxh = (unsigned)(g.sxh * esx);
+  r.yspan = (unsigned)ys; r.byb = (unsigned)(g.syb * esy); r.byn = (unsigned)(g.syn * esy); r.byh = (unsigned)(g.syh * esy);
+  return true;
 }
 
 // kernel 3x3x3, padding 1, temporal stride 1, equal spatial strides in {1,2,4,8}, index ranges the multiply-shift
@@ -816,7 +1033,8 @@ int launch_dw3_run(const void* x, void* y, const float* w, const PoolGeom& g, hi
   const int64_t threads7 = (int64_t)g.B * g.H * g.To * g.Ho * ((g.Wo + 6) / 7) * cpr;
   bool w7 = (g.Wo % 7 == 0) && threads7 >= 131072;
   if (const char* e = getenv("DCC_POOL_WT")) w7 = w7 && atoi(e) == 7;  // A/B knob for scratch/pool_bench.py
-  const RunGeom r = make_run_geom(g, vec, w7 ? 7 : 4);
+  RunGeom r = make_run_geom(g, vec, w7 ? 7 : 4);
+  if (!set_spans(r, sizeof(TD), sizeof(T))) return DCC_ERR_UNSUPPORTED;  // caller falls back to the generic kernel
   const int items = r.runs + (g.has_cls ? g.B * g.H : 0);
   const dim3 grid((items + r.slots - 1) / r.slots);
   const size_t lds = (size_t)27 * g.C * 4;
@@ -847,11 +1065,13 @@ extern "C" int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* arg
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) {
-    // measured (scratch/pool_bench.py): the run kernel wins for stride 1; strided pools read each input at most
-    // once already and are faster with one output per thread
+    // measured (scratch/pool_bench3.py): with buffer-addressed loads the run kernel wins for every stride of the model
     const int S = dw3_stride(g, vec);
-    if (S == 1 && dtype == DCC_BF16) return launch_dw3_run_s<bf16_t, bf16_t, false>(S, x, y, w, g, s);
-    if (S == 1 && dtype == DCC_F32) return launch_dw3_run_s<float, float, false>(S, x, y, w, g, s);
+    int rr = DCC_ERR_UNSUPPORTED;
+    static const int smax = getenv("DCC_POOL_RUN_SMAX") ? atoi(getenv("DCC_POOL_RUN_SMAX")) : 8;
+    if (S >= 1 && S <= smax && dtype == DCC_BF16) rr = launch_dw3_run_s<bf16_t, bf16_t, false>(S, x, y, w, g, s);
+    else if (S >= 1 && S <= smax && dtype == DCC_F32) rr = launch_dw3_run_s<float, float, false>(S, x, y, w, g, s);
+    if (rr != DCC_ERR_UNSUPPORTED) return rr;
   }
   const int64_t total = (int64_t)g.B * (g.To * g.Ho * g.Wo + g.has_cls) * g.H * (g.C / vec);
   dim3 grid(blocks_for(total, 256, 8192));
@@ -892,10 +1112,47 @@ extern "C" int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const
       // stride 1: the mirrored stencil over dy; the run kernel reads through the x-strides and writes through the y-strides
       PoolGeom m = g;
       m.sxb = g.syb; m.sxn = g.syn; m.sxh = g.syh; m.syb = g.sxb; m.syn = g.sxn; m.syh = g.sxh;
-      if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) return launch_dw3_run_s<bf16_t, bf16_t, true>(1, dy, dx, w, m, s);
-      if (dtype == DCC_BF16 && grad_dtype == DCC_F32) return launch_dw3_run_s<bf16_t, float, true>(1, dy, dx, w, m, s);
-      if (dtype == DCC_F32 && grad_dtype == DCC_F32) return launch_dw3_run_s<float, float, true>(1, dy, dx, w, m, s);
+      int rr = DCC_ERR_UNSUPPORTED;
+      if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) rr = launch_dw3_run_s<bf16_t, bf16_t, true>(1, dy, dx, w, m, s);
+      else if (dtype == DCC_BF16 && grad_dtype == DCC_F32) rr = launch_dw3_run_s<bf16_t, float, true>(1, dy, dx, w, m, s);
+      else if (dtype == DCC_F32 && grad_dtype == DCC_F32) rr = launch_dw3_run_s<float, float, true>(1, dy, dx, w, m, s);
+      if (rr != DCC_ERR_UNSUPPORTED) return rr;
     } else if (S > 1) {
+      static const bool quad = !getenv("DCC_POOL_NO_QUAD");
+      if (quad && S == 2 && g.Hs == 2 * g.Ho && g.Ws == 2 * g.Wo) {
+        const bool w7 = (g.Wo % 7 == 0);
+        RunGeom rq = make_run_geom(g, vec, w7 ? 7 : 4);
+        if (set_spans(rq, dtype == DCC_BF16 ? 2 : 4, grad_dtype == DCC_BF16 ? 2 : 4)) {
+          const int items = rq.runs * 2 + (g.has_cls ? g.B * g.H : 0);
+          const dim3 grid((items + rq.slots - 1) / rq.slots);
+          const size_t ldsq = (size_t)27 * g.C * 4;
+#define DW3Q(T_, TD_) do { if (w7) hipLaunchKernelGGL((dw3_bwd_data_s2_kernel<T_, TD_, 7>), grid, dim3(256), ldsq, s, (const TD_*)dy, (T_*)dx, w, rq); \
+                           else hipLaunchKernelGGL((dw3_bwd_data_s2_kernel<T_, TD_, 4>), grid, dim3(256), ldsq, s, (const TD_*)dy, (T_*)dx, w, rq); \
+                           return dcc_check_launch(); } while (0)
+          if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) DW3Q(bf16_t, bf16_t);
+          if (dtype == DCC_BF16 && grad_dtype == DCC_F32) DW3Q(bf16_t, float);
+          if (dtype == DCC_F32 && grad_dtype == DCC_F32) DW3Q(float, float);
+#undef DW3Q
+        }
+      }
+      if (quad && S >= 4) {
+        const bool w7 = (g.Wo % 7 == 0);
+        RunGeom rq = make_run_geom(g, vec, w7 ? 7 : 4);
+        if (set_spans(rq, dtype == DCC_BF16 ? 2 : 4, grad_dtype == DCC_BF16 ? 2 : 4)) {
+          const int items = g.B * g.H * g.T * g.Hs * rq.runsW + (g.has_cls ? g.B * g.H : 0);
+          const dim3 grid((items + rq.slots - 1) / rq.slots);
+          const size_t ldsq = (size_t)27 * g.C * 4;
+#define DW3WD(T_, TD_, S_) do { if (w7) hipLaunchKernelGGL((dw3_bwd_data_wide_kernel<T_, TD_, S_, 7>), grid, dim3(256), ldsq, s, (const TD_*)dy, (T_*)dx, w, rq); \
+                                else hipLaunchKernelGGL((dw3_bwd_data_wide_kernel<T_, TD_, S_, 4>), grid, dim3(256), ldsq, s, (const TD_*)dy, (T_*)dx, w, rq); \
+                                return dcc_check_launch(); } while (0)
+#define DW3WD_S(T_, TD_) do { if (S == 4) DW3WD(T_, TD_, 4); else DW3WD(T_, TD_, 8); } while (0)
+          if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) DW3WD_S(bf16_t, bf16_t);
+          if (dtype == DCC_BF16 && grad_dtype == DCC_F32) DW3WD_S(bf16_t, float);
+          if (dtype == DCC_F32 && grad_dtype == DCC_F32) DW3WD_S(float, float);
+#undef DW3WD_S
+#undef DW3WD
+        }
+      }
       const RunGeom r = make_run_geom(g, vec, 4);
       const int items = g.B * g.H * g.T * g.Hs * g.Ws + (g.has_cls ? g.B * g.H : 0);
       const dim3 grid((items + r.slots - 1) / r.slots);
@@ -934,7 +1191,8 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
     const int S = dw3_stride(g, vec);
     if (S && (256 / (g.C / vec)) >= 3) {
       const bool w7 = (g.Wo % 7 == 0);
-      const RunGeom r = make_run_geom(g, vec, w7 ? 7 : 4);
+      RunGeom r = make_run_geom(g, vec, w7 ? 7 : 4);
+      const bool spans_ok = set_spans(r, dtype == DCC_BF16 ? 2 : 4, grad_dtype == DCC_BF16 ? 2 : 4);
       const int slots3 = r.slots / 3;
       const int total_iters = (r.runs + slots3 - 1) / slots3;
       int nblocks = total_iters < 512 ? total_iters : 512;  // <= DCC_DWCONV_WS_BLOCKS; two 75-KB blocks per CU
@@ -955,7 +1213,8 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
 #define DW3W_S(T_, TD_, W_) do { if (S == 1) DW3W(T_, TD_, 1, W_); else if (S == 2) DW3W(T_, TD_, 2, W_); else if (S == 4) DW3W(T_, TD_, 4, W_); else DW3W(T_, TD_, 8, W_); } while (0)
 #define DW3W_ALL(T_, TD_) do { if (w7) DW3W_S(T_, TD_, 7); else DW3W_S(T_, TD_, 4); } while (0)
       bool done = true;
-      if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) DW3W_ALL(bf16_t, bf16_t);
+      if (!spans_ok) done = false;
+      else if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) DW3W_ALL(bf16_t, bf16_t);
       else if (dtype == DCC_BF16 && grad_dtype == DCC_F32) DW3W_ALL(bf16_t, float);
       else if (dtype == DCC_F32 && grad_dtype == DCC_F32) DW3W_ALL(float, float);
       else done = false;

@@ -53,15 +53,17 @@ def test_layernorm_rejects_unsupported_width():
         K.layernorm_fwd(x.cpu(), torch.ones(3072), torch.zeros(3072), 1e-6)
 
 
-@pytest.mark.parametrize("stride,thw,H,C", [((1, 1, 1), (4, 8, 8), 2, 96), ((1, 2, 2), (4, 8, 8), 1, 96),
-                                            ((1, 4, 4), (2, 16, 16), 2, 96), ((1, 8, 8), (2, 16, 16), 1, 96),
-                                            ((1, 2, 2), (3, 7, 7), 4, 96), ((1, 1, 1), (2, 5, 3), 8, 96)])
+@pytest.mark.parametrize("stride,thw,H,C,B", [((1, 1, 1), (4, 8, 8), 2, 96, 2), ((1, 2, 2), (4, 8, 8), 1, 96, 2),
+                                              ((1, 4, 4), (2, 16, 16), 2, 96, 2), ((1, 8, 8), (2, 16, 16), 1, 96, 2),
+                                              ((1, 2, 2), (3, 7, 7), 4, 96, 2), ((1, 1, 1), (2, 5, 3), 8, 96, 2),
+                                              # runs of 7 columns (grids 56/28/14/7) incl. the stride-2 row-run gradient
+                                              ((1, 2, 2), (2, 14, 14), 2, 96, 3), ((1, 1, 1), (3, 14, 14), 4, 96, 33),
+                                              ((1, 2, 2), (4, 56, 56), 2, 96, 13), ((1, 4, 4), (2, 28, 28), 1, 96, 2)])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
-def test_depthwise_pool_fwd_bwd(stride, thw, H, C, dtype, tol):
+def test_depthwise_pool_fwd_bwd(stride, thw, H, C, B, dtype, tol):
     """Pool's Conv3d(groups=C, k=3, p=1, stride) on [B, N, H, C] token views with class-token bypass (R4)."""
     from deepcoro_clip_amd import kernels as K
 
-    B = 2
     g = _gen(7)
     geo = K.PoolGeom(B, H, C, thw, (3, 3, 3), stride, (1, 1, 1), True)
     x0 = torch.randn(B, geo.n_in, H, C, generator=g).to(dtype).float()
