@@ -288,24 +288,27 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const TD* __rest
 }
 
 // dw[c][tap] += sum_b ws[b][tap][c]; block = 32 outputs x 8 interleaved block-groups (coalesced 128-byte rows,
-// 8 loads in flight per thread), folded through LDS.
+// 8 loads in flight per thread), folded through LDS; the partials are split over gridDim.y slices (one slice would
+// walk them in latency-bound rounds of 64) and each slice adds its sum with one atomic per output.
 __global__ __launch_bounds__(256) void dwconv_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                             int nblocks, int taps, int C) {
-  __shared__ float part[8][32];
+  __shared__ float part[8][33];
   const int il = threadIdx.x & 31, bg = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + il;
   const int n = taps * C;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
   float acc = 0.0f;
   if (i < n) {
-    int b = bg;
-    for (; b + 56 < nblocks; b += 64) {
+    int b = b0 + bg;
+    for (; b + 56 < b1; b += 64) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)(b + 8 * u) * n + i];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; b < nblocks; b += 8) acc += ws[(int64_t)b * n + i];
+    for (; b < b1; b += 8) acc += ws[(int64_t)b * n + i];
   }
   part[bg][il] = acc;
   __syncthreads();
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256) void dwconv_reduce_kernel(const float* __restr
 #pragma unroll
     for (int u = 0; u < 8; ++u) t += part[u][il];
     const int k = i / C, cc = i % C;
-    dw[cc * taps + k] += t;
+    atomicAdd(dw + cc * taps + k, t);
   }
 }
 
@@ -1224,7 +1227,7 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
       if (done) {
         rc = dcc_check_launch();
         if (rc) return rc;
-        hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((27 * g.C + 31) / 32), dim3(256), 0, s, workspace, dw, nblocks, 27, g.C);
+        hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((27 * g.C + 31) / 32, (nblocks + 63) / 64), dim3(256), 0, s, workspace, dw, nblocks, 27, g.C);
         return dcc_check_launch();
       }
     }
@@ -1246,6 +1249,6 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
   else return DCC_ERR_UNSUPPORTED;
   rc = dcc_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((taps * g.C + 31) / 32), dim3(256), 0, s, workspace, dw, (int)grid.x, taps, g.C);
+  hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((taps * g.C + 31) / 32, (grid.x + 63) / 64), dim3(256), 0, s, workspace, dw, (int)grid.x, taps, g.C);
   return dcc_check_launch();
 }

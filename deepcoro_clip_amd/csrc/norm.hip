@@ -100,17 +100,29 @@ template <typename TD, int VEC> __device__ __forceinline__ void store_vecf(TD* p
   }
 }
 
+// raw 16-byte registers -> VEC floats
+template <typename TD, int VEC> __device__ __forceinline__ void unpack_f32(const f32x4* r, float (&o)[VEC]) {
+  if constexpr (sizeof(TD) == 2) {
+    const bf16x8 t = __builtin_bit_cast(bf16x8, r[0]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)t[e];
+  } else {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) { o[4 * q] = r[q][0]; o[4 * q + 1] = r[q][1]; o[4 * q + 2] = r[q][2]; o[4 * q + 3] = r[q][3]; }
+  }
+}
+
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dgamma += dy * xhat, dbeta += dy
 // TD = element type of dy / dx (may be fp32 while x is bf16, e.g. gradients reduced with atomics).
 // Parameter gradients: registers over the row loop -> LDS per block -> ONE global atomic per column per block
 // (a few hundred blocks), instead of per-wave global atomics that serialise on C addresses.
-template <typename T, typename TD, int LPR, int ITERS>
+template <typename T, typename TD, int LPR, int ITERS, int U>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const T* __restrict__ x,
                                                      int64_t ldx, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      TD* __restrict__ dx, int64_t lddx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int64_t rows, int C,
-                                                     const TD* __restrict__ dres) {
+                                                     const TD* __restrict__ dres, float* __restrict__ ws) {
   constexpr int VEC = Vec16<T>::N;
   constexpr int RPW = 64 / LPR;
   using V = vec16_t<T>;
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.0f;
   __syncthreads();
   const int lane = threadIdx.x & 63, sub = lane % LPR, rw = lane / LPR;
-  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int nch = C / VEC;
   float gam[ITERS][VEC], dg[ITERS][VEC], db[ITERS][VEC];
@@ -132,51 +144,86 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
       db[it][e] = 0.0f;
     }
   }
-  for (int64_t r0 = wave0 * RPW; r0 < rows; r0 += nwaves * RPW) {
-    const int64_t row = r0 + rw;
-    const bool rok = row < rows;
-    const float mu = rok ? mean[row] : 0.0f, rs = rok ? rstd[row] : 0.0f;
-    float xh[ITERS][VEC], g[ITERS][VEC];
-    float s1 = 0.0f, s2 = 0.0f;
+  // Branch-free row loop.  A wave handles U groups of RPW rows per iteration through buffer descriptors based at its
+  // first row (wave-uniform, so any tensor size works with 32-bit offsets): rows past the end and the idle lanes of a
+  // narrow row read zeros / drop their stores through out-of-range offsets, so every load of the iteration is in flight
+  // before the first reduction — the kernel is bound by bytes in flight, and conditional loads made the compiler wait
+  // for each one inside its branch.
+  constexpr int G = RPW * U;
+  constexpr unsigned NOPE = 0xF0000000u;
+  auto rsrc = [](const void* p, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes), 0x00020000);
+  };
+  for (int64_t r0 = wave0 * G; r0 < rows; r0 += nwaves * G) {
+    const int64_t nrow = rows - r0 < G ? rows - r0 : G;
+    const __amdgpu_buffer_rsrc_t rsx = rsrc(x + r0 * ldx, ((nrow - 1) * ldx + C) * (int64_t)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rsy = rsrc(dy + r0 * lddy, ((nrow - 1) * lddy + C) * (int64_t)sizeof(TD));
+    const __amdgpu_buffer_rsrc_t rsd = rsrc(dx + r0 * lddx, ((nrow - 1) * lddx + C) * (int64_t)sizeof(TD));
+    const __amdgpu_buffer_rsrc_t rsr = rsrc(dres ? dres + r0 * lddx : nullptr, dres ? ((nrow - 1) * lddx + C) * (int64_t)sizeof(TD) : 0);
+    const __amdgpu_buffer_rsrc_t rsm = rsrc(mean + r0, nrow * 4), rss = rsrc(rstd + r0, nrow * 4);
+    f32x4 tx[U][ITERS][sizeof(T) * VEC / 16], td[U][ITERS][sizeof(TD) * VEC / 16], tr[U][ITERS][sizeof(TD) * VEC / 16];
+    float mu[U], rs[U];
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const int c = it * LPR + sub;
-      if (rok && c < nch) {
-        const V tx = *reinterpret_cast<const V*>(x + row * ldx + c * VEC);
-        float d[VEC];
-        load_vecf<TD, VEC>(dy + row * lddy + c * VEC, d);
+    for (int u = 0; u < U; ++u) {
+      const int lrow = u * RPW + rw;
+      mu[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsm, lrow * 4, 0, 0));
+      rs[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rss, lrow * 4, 0, 0));
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int c = it * LPR + sub;
+        const bool live = c < nch;
+        const unsigned ox = live ? (unsigned)((lrow * ldx + c * VEC) * sizeof(T)) : NOPE;
+        const unsigned oy = live ? (unsigned)((lrow * lddy + c * VEC) * sizeof(TD)) : NOPE;
+        const unsigned od = live ? (unsigned)((lrow * lddx + c * VEC) * sizeof(TD)) : NOPE;
+#pragma unroll
+        for (int q = 0; q < (int)(sizeof(T) * VEC / 16); ++q) tx[u][it][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, ox, 16 * q, 0));
+#pragma unroll
+        for (int q = 0; q < (int)(sizeof(TD) * VEC / 16); ++q) {
+          td[u][it][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, oy, 16 * q, 0));
+          tr[u][it][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, od, 16 * q, 0));
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int lrow = u * RPW + rw;
+      float xh[ITERS][VEC], g[ITERS][VEC];
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        float xv[VEC], d[VEC];
+        unpack_f32<T, VEC>(tx[u][it], xv);
+        unpack_f32<TD, VEC>(td[u][it], d);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          xh[it][e] = (to_f32(tx[e]) - mu) * rs;
+          xh[it][e] = (xv[e] - mu[u]) * rs[u];
           g[it][e] = d[e] * gam[it][e];
           s1 += g[it][e];
           s2 += g[it][e] * xh[it][e];
           dg[it][e] += d[e] * xh[it][e];
           db[it][e] += d[e];
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) { xh[it][e] = 0.0f; g[it][e] = 0.0f; }
       }
-    }
 #pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    s1 /= C; s2 /= C;
-    if (rok) {
+      for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      s1 /= C; s2 /= C;
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         const int c = it * LPR + sub;
-        if (c < nch) {
-          float o[VEC];
+        float o[VEC], rr[VEC];
+        unpack_f32<TD, VEC>(tr[u][it], rr);  // gradient arriving through the other use of x (residual / skip path); zeros without dres
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) o[e] = rs * (g[it][e] - s1 - xh[it][e] * s2);
-          if (dres) {  // gradient arriving through the other use of x (residual / skip path): summed here, not by autograd
-            float rr[VEC];
-            load_vecf<TD, VEC>(dres + row * lddx + c * VEC, rr);
+        for (int e = 0; e < VEC; ++e) o[e] = rs[u] * (g[it][e] - s1 - xh[it][e] * s2) + rr[e];
+        const unsigned od = c < nch ? (unsigned)((lrow * lddx + c * VEC) * sizeof(TD)) : NOPE;
+        if constexpr (sizeof(TD) == 2) {
+          bf16x8 t;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) o[e] += rr[e];
-          }
-          store_vecf<TD, VEC>(dx + row * lddx + c * VEC, o);
+          for (int e = 0; e < 8; ++e) t[e] = (bf16_t)o[e];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rsd, od, 0, 0);
+        } else {
+#pragma unroll
+          for (int q = 0; q < VEC / 4; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]}), rsd, od, 16 * q, 0);
         }
       }
     }
@@ -206,9 +253,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += blockDim.x) {
-    if (dgamma) atomicAdd(dgamma + i, red[i]);
-    if (dbeta) atomicAdd(dbeta + i, red[C + i]);
+  if (!ws) {  // no workspace: one atomic per column per block straight into the gradients (grid capped at 512 blocks)
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+      if (dgamma) atomicAdd(dgamma + i, red[i]);
+      if (dbeta) atomicAdd(dbeta + i, red[C + i]);
+    }
+    return;
+  }
+  // With a workspace: plain stores of the block partial, folded by ln_reduce_kernel (no atomics, so the grid size is
+  // not tied to an atomic tail: ~18 ns per block on the few L2 channels that hold dgamma / dbeta)
+  float* part = ws + (size_t)blockIdx.x * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) part[i] = red[i];
+}
+
+// out[i] += sum_b ws[b][i], i < 2C (first C -> dgamma, rest -> dbeta); 32 columns x 8 partial groups per block, the
+// partials split over gridDim.y slices (a single slice walks them in latency-bound rounds of 64)
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int nblocks, int C) {
+  __shared__ float part[8][33];
+  const int il = threadIdx.x & 31, bg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + il, n = 2 * C;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+  float acc = 0.0f;
+  if (i < n) {
+    int b = b0 + bg;
+    for (; b + 56 < b1; b += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)(b + 8 * u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < b1; b += 8) acc += ws[(int64_t)b * n + i];
+  }
+  part[bg][il] = acc;
+  __syncthreads();
+  if (bg == 0 && i < n) {
+    float t = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += part[u][il];
+    if (i < C) { if (dgamma) atomicAdd(dgamma + i, t); }
+    else if (dbeta) atomicAdd(dbeta + i - C, t);
   }
 }
 
@@ -225,6 +311,13 @@ inline unsigned grid_for(int64_t rows, int rpw) {
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;
+}
+
+inline unsigned lnb_grid(int64_t rows, int rows_per_wave_iter, unsigned cap) {
+  const int64_t per_block = (int64_t)rows_per_wave_iter * 4;
+  int64_t blocks = (rows + per_block - 1) / per_block;
+  if (blocks > cap) blocks = cap;
+  return (unsigned)(blocks < 1 ? 1 : blocks);
 }
 
 template <typename T>
@@ -247,11 +340,20 @@ int ln_fwd_t(const void* x, int64_t ldx, void* y, int64_t ldy, const float* g, c
 template <typename T, typename TD>
 int ln_bwd_t(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean, const float* rstd,
              const float* g, void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int C, const void* dres,
-             hipStream_t st) {
+             float* ws, hipStream_t st) {
   int lpr, iters;
   if (pick(C / Vec16<T>::N, lpr, iters)) return DCC_ERR_UNSUPPORTED;
   const TD* dyp = (const TD*)dy; const T* xp = (const T*)x; TD* dxp = (TD*)dx; const TD* drp = (const TD*)dres;
-#define LN_B(LP, IT) hipLaunchKernelGGL((ln_bwd_kernel<T, TD, LP, IT>), dim3(grid_for(rows, 64 / LP) > 512 ? 512 : grid_for(rows, 64 / LP)), dim3(256), 2 * C * sizeof(float), st, dyp, lddy, xp, ldx, mean, rstd, g, dxp, lddx, dgamma, dbeta, rows, C, drp)
+  static const unsigned lnb_cap = getenv("DCC_LNB_CAP") ? (unsigned)atoi(getenv("DCC_LNB_CAP")) : 512u;
+  // measured (scratch/ln_bench.py): 512 blocks up to ~30 M elements, 1024 beyond (block 0/1 per-head norms)
+  static const unsigned lnb_cap_env = getenv("DCC_LNB_CAP_WS") ? (unsigned)atoi(getenv("DCC_LNB_CAP_WS")) : 0u;
+  const unsigned lnb_cap_ws = lnb_cap_env ? lnb_cap_env : (rows * C >= (32 << 20) ? 1024u : 512u);
+  const unsigned ws_fit = (1u << 20) / (unsigned)(2 * C);  // block partials the workspace holds (DCC_LN_WS_FLOATS in include/dcc.h)
+  const unsigned ws_cap = ws_fit < lnb_cap_ws ? ws_fit : lnb_cap_ws;
+  unsigned nb = 0;
+  static const int lnb_u = getenv("DCC_LNB_U") ? atoi(getenv("DCC_LNB_U")) : 2;
+#define LN_BU(LP, IT, UU) hipLaunchKernelGGL((ln_bwd_kernel<T, TD, LP, IT, UU>), dim3(nb = lnb_grid(rows, 64 / LP * UU, ws ? ws_cap : lnb_cap)), dim3(256), 2 * C * sizeof(float), st, dyp, lddy, xp, ldx, mean, rstd, g, dxp, lddx, dgamma, dbeta, rows, C, drp, ws)
+#define LN_B(LP, IT) do { if (lnb_u == 4 && IT == 1) LN_BU(LP, IT, 4); else if (lnb_u >= 2 && IT <= 2) LN_BU(LP, IT, 2); else LN_BU(LP, IT, 1); } while (0)
   if (lpr == 16) LN_B(16, 1);
   else if (lpr == 32) LN_B(32, 1);
   else if (iters == 1) LN_B(64, 1);
@@ -259,6 +361,10 @@ int ln_bwd_t(const void* dy, int64_t lddy, const void* x, int64_t ldx, const flo
   else if (iters == 3) LN_B(64, 3);
   else LN_B(64, 4);
 #undef LN_B
+#undef LN_BU
+  int rc = dcc_check_launch();
+  if (rc || !ws) return rc;
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3((2 * C + 31) / 32, (nb + 63) / 64), dim3(256), 0, st, ws, dgamma, dbeta, (int)nb, C);
   return dcc_check_launch();
 }
 
@@ -279,8 +385,8 @@ extern "C" int dcc_layernorm_fwd(const void* x, int64_t ldx, void* y, int64_t ld
 // dgamma / dbeta are ACCUMULATED into (fp32, caller zeroes or owns the running gradient).
 extern "C" int dcc_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean,
                                  const float* rstd, const float* gamma, void* dx, int64_t lddx, float* dgamma,
-                                 float* dbeta, const void* dres, int64_t rows, int C, int dtype, int grad_dtype,
-                                 void* stream) {
+                                 float* dbeta, const void* dres, float* workspace, int64_t rows, int C, int dtype,
+                                 int grad_dtype, void* stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !dx || rows <= 0 || C <= 0) return DCC_ERR_ARG;
   const int vec = dtype == DCC_BF16 ? 8 : 4;
   if ((C % vec) || (ldx % vec) || ((uintptr_t)x & 15)) return DCC_ERR_UNSUPPORTED;
@@ -288,10 +394,10 @@ extern "C" int dcc_layernorm_bwd(const void* dy, int64_t lddy, const void* x, in
   if ((lddy % gvec) || (lddx % gvec) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) || ((uintptr_t)dres & 15)) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DCC_BF16 && grad_dtype == DCC_BF16)
-    return ln_bwd_t<bf16_t, bf16_t>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, dres, st);
+    return ln_bwd_t<bf16_t, bf16_t>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, dres, workspace, st);
   if (dtype == DCC_BF16 && grad_dtype == DCC_F32)
-    return ln_bwd_t<bf16_t, float>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, dres, st);
+    return ln_bwd_t<bf16_t, float>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, dres, workspace, st);
   if (dtype == DCC_F32 && grad_dtype == DCC_F32)
-    return ln_bwd_t<float, float>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, dres, st);
+    return ln_bwd_t<float, float>(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta, rows, C, dres, workspace, st);
   return DCC_ERR_UNSUPPORTED;
 }

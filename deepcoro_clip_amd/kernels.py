@@ -247,6 +247,9 @@ def layernorm_fwd(x2d: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ep
     return out, mean, rstd
 
 
+_LN_WS: dict = {}
+
+
 def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dgamma, dbeta, dx: torch.Tensor | None = None,
                   dres: torch.Tensor | None = None):
     """dgamma/dbeta (fp32) are accumulated into. dy2d may be fp32 while x is bf16; dx takes dy's dtype.
@@ -258,9 +261,14 @@ def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dgamma, dbeta, dx: torch.Tensor 
         dx = torch.empty((rows, C), device=x2d.device, dtype=dy2d.dtype)
     assert dx.dtype == dy2d.dtype and dx.stride(1) == 1
     assert dres is None or (dres.shape == (rows, C) and dres.dtype == dx.dtype and dres.stride() == dx.stride())
+    stream = L.stream()
+    key = (dy2d.device.index, stream.value)  # block partials of dgamma/dbeta; one per stream (the branches overlap)
+    ws = _LN_WS.get(key)
+    if ws is None:
+        ws = _LN_WS[key] = torch.empty(1 << 20, device=dy2d.device, dtype=torch.float32)  # DCC_LN_WS_FLOATS
     L.call("dcc_layernorm_bwd", L.ptr(dy2d), dy2d.stride(0), L.ptr(x2d), x2d.stride(0), L.ptr(mean), L.ptr(rstd),
-           L.ptr(gamma), L.ptr(dx), dx.stride(0), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), rows, C, L.dt(x2d),
-           L.dt(dy2d), L.stream())
+           L.ptr(gamma), L.ptr(dx), dx.stride(0), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), L.ptr(ws), rows, C,
+           L.dt(x2d), L.dt(dy2d), stream)
     return dx
 
 

@@ -94,10 +94,14 @@ int dcc_relpos_kaug(void* Kf, const int* dims, const int64_t* strides, int dtype
 int dcc_layernorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
                       float* mean, float* rstd, int64_t rows, int C, float eps, int dtype, void* stream);
 /* dres (nullable, dx's type and leading dimension): gradient reaching x through its OTHER use in a transformer block
- * (the residual / skip branch), added into dx here instead of by a separate autograd add kernel. */
+ * (the residual / skip branch), added into dx here instead of by a separate autograd add kernel.
+ * workspace (nullable): DCC_LN_WS_FLOATS fp32 of scratch owned by one stream (no initialisation needed).  With it every
+ * block stores its dgamma / dbeta partial and a second small kernel folds them (no atomics, grid up to 2048 blocks);
+ * without it every block adds straight into dgamma / dbeta with atomics (grid capped at 512 blocks). */
+#define DCC_LN_WS_FLOATS (1 << 20)
 int dcc_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean, const float* rstd,
                       const float* gamma, void* dx, int64_t lddx, float* dgamma, float* dbeta, const void* dres,
-                      int64_t rows, int C, int dtype, int grad_dtype, void* stream);
+                      float* workspace, int64_t rows, int C, int dtype, int grad_dtype, void* stream);
 
 /* ---- convolution-shaped ops (csrc/conv.hip) ------------------------------------------------
  * dcc_im2col3d: operand of the conv_proj GEMM; video is NDHWC fp32 as produced by the permute+view of
