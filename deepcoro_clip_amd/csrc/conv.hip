@@ -50,6 +50,65 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__
   }
 }
 
+struct FastDiv { unsigned d; unsigned long long m; };
+inline FastDiv mkdiv(unsigned d) { FastDiv f; f.d = d ? d : 1; f.m = ((1ull << 40) / f.d) + 1; return f; }
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return (unsigned)(((unsigned long long)n * f.m) >> 40); }
+
+// Chunked variant (the one the patch embedding uses): a thread owns one 16-byte chunk of the column index and
+// walks tokens, so the (kt, kh, kw, c) decomposition of its CV elements is done once, token coordinates come from
+// multiply-shift divisions, padding reads zeros through out-of-range buffer offsets and the row is written with
+// 16-byte stores (the generic kernel spends ~40 instructions and a 2-byte store per element).
+struct Im2colGeom {
+  int B, Tn, Hn, Wn, Cin, KT, KH, KW, st, sh, sw, pt, ph, pw, To, Ho, Wo, Kp;
+  int cpt, tpb;          // chunks per token, tokens per block
+  unsigned ntok, xbytes;
+  FastDiv d_cpt, d_Wo, d_Ho, d_To;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3d_chunk_kernel(const float* __restrict__ x, T* __restrict__ col, Im2colGeom g) {
+  constexpr int CV = Vec16<T>::N;
+  const unsigned tl = fdiv(threadIdx.x, g.d_cpt);
+  const int ch = threadIdx.x - tl * g.cpt;
+  if ((int)tl >= g.tpb) return;
+  const int run = g.KW * g.Cin, K = g.KT * g.KH * run;
+  int doff[CV], kt[CV], kh[CV], kw[CV];
+#pragma unroll
+  for (int e = 0; e < CV; ++e) {
+    const int i = ch * CV + e;
+    if (i < K) {
+      const int r = i % run;
+      kh[e] = (i / run) % g.KH; kt[e] = i / (run * g.KH); kw[e] = r / g.Cin;
+      doff[e] = ((kt[e] * g.Hn + kh[e]) * g.Wn + kw[e]) * g.Cin + (r % g.Cin);
+    } else { kt[e] = 1 << 20; kh[e] = kw[e] = doff[e] = 0; }  // zero padding of the column index: never in range
+  }
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xbytes, 0x00020000);
+  for (unsigned tok = blockIdx.x * g.tpb + tl; tok < g.ntok; tok += gridDim.x * g.tpb) {
+    const unsigned q1 = fdiv(tok, g.d_Wo);
+    const int wo = tok - q1 * g.Wo;
+    const unsigned q2 = fdiv(q1, g.d_Ho);
+    const int ho = q1 - q2 * g.Ho;
+    const unsigned b = fdiv(q2, g.d_To);
+    const int to = q2 - b * g.To;
+    const int t0 = to * g.st - g.pt, h0 = ho * g.sh - g.ph, w0 = wo * g.sw - g.pw;
+    const int obase = (((int)b * g.Tn + t0) * g.Hn + h0) * g.Wn * g.Cin + w0 * g.Cin;
+    float v[CV];
+#pragma unroll
+    for (int e = 0; e < CV; ++e) {
+      const bool ok = (unsigned)(t0 + kt[e]) < (unsigned)g.Tn && (unsigned)(h0 + kh[e]) < (unsigned)g.Hn && (unsigned)(w0 + kw[e]) < (unsigned)g.Wn;
+      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, ok ? (unsigned)(obase + doff[e]) * 4u : 0xF0000000u, 0, 0));
+    }
+    T* dst = col + (int64_t)tok * g.Kp + ch * CV;
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      *reinterpret_cast<bf16x8*>(dst) = o;
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+  }
+}
+
 // ---------------------------------------------------------------- depthwise conv / max pool forward
 // one thread = one 16-byte channel chunk of one output token-head.
 template <typename T, bool MAXPOOL>
@@ -333,9 +392,6 @@ __global__ __launch_bounds__(256) void dwconv_reduce_kernel(const float* __restr
 //     strided pool enumerates exactly the taps that reach an input position (1-2 per axis instead of 3 tests);
 //   * the weight gradient keeps one temporal tap per thread (72 accumulators), folds the threads of a block
 //     through LDS without atomics and writes one partial per block for dwconv_reduce_kernel.
-struct FastDiv { unsigned d; unsigned long long m; };
-inline FastDiv mkdiv(unsigned d) { FastDiv f; f.d = d ? d : 1; f.m = ((1ull << 40) / f.d) + 1; return f; }
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return (unsigned)(((unsigned long long)n * f.m) >> 40); }
 
 struct RunGeom {
   PoolGeom g;
@@ -1018,6 +1074,21 @@ extern "C" int dcc_im2col3d(const float* x, void* col, int B, int T, int H, int 
   const int64_t ntok = (int64_t)B * To * Ho * Wo;
   dim3 grid((unsigned)((ntok + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int cv = dtype == DCC_BF16 ? 8 : 4;
+    const int64_t xelems = (int64_t)B * T * H * W * Cin;
+    if ((dtype == DCC_BF16 || dtype == DCC_F32) && Kp % cv == 0 && Kp / cv <= 256 && xelems * 4 < 0x7fffffffLL && ntok < (1LL << 30) &&
+        (((uintptr_t)col) & 15) == 0) {
+      Im2colGeom g{B, T, H, W, Cin, KT, KH, KW, st, sh, sw, pt, ph, pw, To, Ho, Wo, Kp};
+      g.cpt = Kp / cv; g.tpb = 256 / g.cpt; g.ntok = (unsigned)ntok; g.xbytes = (unsigned)(xelems * 4);
+      g.d_cpt = mkdiv(g.cpt); g.d_Wo = mkdiv(Wo); g.d_Ho = mkdiv(Ho); g.d_To = mkdiv(To);
+      int64_t nb = (ntok + g.tpb - 1) / g.tpb;
+      if (nb > 16384) nb = 16384;
+      if (dtype == DCC_BF16) hipLaunchKernelGGL((im2col3d_chunk_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, s, x, (bf16_t*)col, g);
+      else hipLaunchKernelGGL((im2col3d_chunk_kernel<float>), dim3((unsigned)nb), dim3(256), 0, s, x, (float*)col, g);
+      return dcc_check_launch();
+    }
+  }
   if (dtype == DCC_BF16)
     hipLaunchKernelGGL((im2col3d_kernel<bf16_t>), grid, dim3(256), 0, s, x, (bf16_t*)col, B, T, H, W, Cin, KT, KH, KW,
                        st, sh, sw, pt, ph, pw, To, Ho, Wo, Kp);

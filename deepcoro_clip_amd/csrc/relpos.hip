@@ -55,26 +55,30 @@ __global__ __launch_bounds__(256) void relpos_gather_kernel(T* __restrict__ Qf, 
   const int hd = row - bn * g.H;
   const unsigned b = bn / Nq;
   const int n = bn - b * Nq;
+  // Branch-free: the 8 table lookups are issued together, then the 8 gathers (an if-chain with a load in every arm made
+  // the compiler wait for each load inside its branch: 16 serialised round trips per thread).
   float v[8];
+  const bool tokrow = !(g.has_cls && n == 0);
+  const int i = tokrow ? n - g.has_cls : 0;
+  const int t = i / (g.qw * g.qh), r = i - t * (g.qw * g.qh);
+  const int hh = r / g.qw, w = r - hh * g.qw;
+  const T* prow = P + (int64_t)row * g.L;
+  int l[8];
+  bool ok[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-  if (!(g.has_cls && n == 0)) {
-    const int i = n - g.has_cls;
-    const int t = i / (g.qw * g.qh), r = i - t * (g.qw * g.qh);
-    const int hh = r / g.qw, w = r - hh * g.qw;
-    const T* prow = P + (int64_t)row * g.L;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int j = j0 + e;
-      if (j < g.kh + g.kw + g.kt) {
-        int l;
-        if (j < g.kh) l = idx_h[hh * g.kh + j];
-        else if (j < g.kh + g.kw) l = g.Lh + idx_w[w * g.kw + (j - g.kh)];
-        else l = g.Lh + g.Lw + idx_t[t * g.kt + (j - g.kh - g.kw)];
-        v[e] = to_f32(prow[l]) * inv_scale;
-      }
-    }
+  for (int e = 0; e < 8; ++e) {
+    const int j = j0 + e;
+    ok[e] = tokrow && j < g.kh + g.kw + g.kt;
+    const int ax = (j >= g.kh) + (j >= g.kh + g.kw);
+    const int* tp = ax == 0 ? idx_h : (ax == 1 ? idx_w : idx_t);
+    const int off = ax == 0 ? hh * g.kh + j : (ax == 1 ? w * g.kw + (j - g.kh) : t * g.kt + (j - g.kh - g.kw));
+    l[e] = tp[ok[e] ? off : 0] + (ax == 0 ? 0 : (ax == 1 ? g.Lh : g.Lh + g.Lw));
   }
+  T pv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pv[e] = prow[ok[e] ? l[e] : 0];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = ok[e] ? to_f32(pv[e]) * inv_scale : 0.0f;
   store8<T>(Qf + b * g.sb + (int64_t)n * g.sn + hd * g.sh + g.D + j0, v);
 }
 
@@ -94,25 +98,27 @@ __global__ __launch_bounds__(256) void relpos_scatter_kernel(const T* __restrict
   const unsigned b = bn / Nq;
   const int n = bn - b * Nq;
   float v[8];
+  const bool tokrow = !(g.has_cls && n == 0);
+  const int i = tokrow ? n - g.has_cls : 0;
+  const int t = i / (g.qw * g.qh), r = i - t * (g.qw * g.qh);
+  const int hh = r / g.qw, w = r - hh * g.qw;
+  const T* src = dQf + b * g.sb + (int64_t)n * g.sn + hd * g.sh + g.D;
+  int j[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-  if (!(g.has_cls && n == 0)) {
-    const int i = n - g.has_cls;
-    const int t = i / (g.qw * g.qh), r = i - t * (g.qw * g.qh);
-    const int hh = r / g.qw, w = r - hh * g.qw;
-    const T* src = dQf + b * g.sb + (int64_t)n * g.sn + hd * g.sh + g.D;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int l = l0 + e;
-      if (l < g.Lh + g.Lw + g.Lt) {
-        int j;
-        if (l < g.Lh) { j = inv_h[hh * g.Lh + l]; }
-        else if (l < g.Lh + g.Lw) { j = inv_w[w * g.Lw + (l - g.Lh)]; if (j >= 0) j += g.kh; }
-        else { j = inv_t[t * g.Lt + (l - g.Lh - g.Lw)]; if (j >= 0) j += g.kh + g.kw; }
-        if (j >= 0) v[e] = to_f32(src[j]) * inv_scale;
-      }
-    }
+  for (int e = 0; e < 8; ++e) {  // branch-free, see relpos_gather_kernel
+    const int l = l0 + e;
+    const bool ok = tokrow && l < g.Lh + g.Lw + g.Lt;
+    const int ax = (l >= g.Lh) + (l >= g.Lh + g.Lw);
+    const int* tp = ax == 0 ? inv_h : (ax == 1 ? inv_w : inv_t);
+    const int off = ax == 0 ? hh * g.Lh + l : (ax == 1 ? w * g.Lw + (l - g.Lh) : t * g.Lt + (l - g.Lh - g.Lw));
+    const int jj = tp[ok ? off : 0];
+    j[e] = (ok && jj >= 0) ? jj + (ax == 0 ? 0 : (ax == 1 ? g.kh : g.kh + g.kw)) : -1;
   }
+  T sv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sv[e] = src[j[e] >= 0 ? j[e] : 0];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = j[e] >= 0 ? to_f32(sv[e]) * inv_scale : 0.0f;
   store8<T>(dP + (int64_t)row * g.L + l0, v);
 }
 
