@@ -202,8 +202,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         m, _ = runner._train_step(**batch)
+    t_host = time.perf_counter() - t0  # launches enqueued; the metrics are not read, so nothing drained the queue yet
     barrier()
     dt = time.perf_counter() - t0
+    if rank == 0:
+        print(f"[bench] host enqueue {1e3 * t_host / args.steps:.2f} ms/step, wall {1e3 * dt / args.steps:.2f} ms/step", file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -145,16 +145,29 @@ __global__ void broadcast_row_kernel(const float* __restrict__ src, T* __restric
     dst[(i / C) * ld + (i % C)] = from_f32<T>(src[i % C]);
 }
 
-// y[b][d] = mean_n x[b][n][d]
+// y[b][d] = mean_n x[b][n][d]; block = (b, 64 columns), the 4 waves take interleaved token rows with 8 loads in
+// flight each and fold through LDS (one thread per output walked the N rows in a serial latency chain)
 template <typename T>
-__global__ void token_mean_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int N, int D) {
-  const int64_t total = (int64_t)B * D;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = i / D, d = i % D;
-    float acc = 0.0f;
-    for (int n = 0; n < N; ++n) acc += to_f32(x[((int64_t)b * N + n) * D + d]);
-    y[i] = from_f32<T>(acc / N);
+__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int N, int D) {
+  __shared__ float part[4][64];
+  const int nd = (D + 63) / 64;
+  const int b = blockIdx.x / nd, d = (blockIdx.x - b * nd) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  float acc = 0.0f;
+  if (d < D) {
+    const T* xb = x + (int64_t)b * N * D + d;
+    int n = g;
+    for (; n + 28 < N; n += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = to_f32(xb[(int64_t)(n + 4 * u) * D]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; n < N; n += 4) acc += to_f32(xb[(int64_t)n * D]);
   }
+  part[g][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (g == 0 && d < D) y[(int64_t)b * D + d] = from_f32<T>((part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / N);
 }
 template <typename T>
 __global__ void token_mean_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int N, int D) {
@@ -418,10 +431,10 @@ extern "C" int dcc_token_mean(const void* in, void* out, int B, int N, int D, in
   dim3 g(gs_blocks(total));
   if (dtype == DCC_BF16) {
     if (backward) hipLaunchKernelGGL((token_mean_bwd_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, B, N, D);
-    else hipLaunchKernelGGL((token_mean_fwd_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, B, N, D);
+    else hipLaunchKernelGGL((token_mean_fwd_kernel<bf16_t>), dim3(B * ((D + 63) / 64)), dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, B, N, D);
   } else if (dtype == DCC_F32) {
     if (backward) hipLaunchKernelGGL((token_mean_bwd_kernel<float>), g, dim3(256), 0, ST, (const float*)in, (float*)out, B, N, D);
-    else hipLaunchKernelGGL((token_mean_fwd_kernel<float>), g, dim3(256), 0, ST, (const float*)in, (float*)out, B, N, D);
+    else hipLaunchKernelGGL((token_mean_fwd_kernel<float>), dim3(B * ((D + 63) / 64)), dim3(256), 0, ST, (const float*)in, (float*)out, B, N, D);
   } else return DCC_ERR_UNSUPPORTED;
   return dcc_check_launch();
 }

@@ -77,12 +77,14 @@ class GradClipper:
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
         self.coef = torch.ones(1, device=dev, dtype=torch.float32)
         self.norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._base: np.ndarray | None = None
 
     def _desc(self) -> np.ndarray:
-        d = np.zeros(len(self.params), dtype=_DESC)
-        for i, p in enumerate(self.params):
-            d[i]["g"] = _grad_ptr(p)
-            d[i]["n"] = p.numel()
+        if self._base is None:
+            self._base = np.zeros(len(self.params), dtype=_DESC)
+            self._base["n"] = [p.numel() for p in self.params]
+        d = self._base.copy()
+        d["g"] = np.fromiter((_grad_ptr(p) for p in self.params), dtype=np.uint64, count=len(self.params))
         return d
 
     def clip_(self, max_norm: float, scale: bool = True) -> torch.Tensor:
@@ -113,6 +115,7 @@ class HipAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._table: _TensorTable | None = None
         self._plist: list[torch.Tensor] = []
+        self._plan: dict | None = None
 
     @classmethod
     def adopt(cls, optimizer: torch.optim.Optimizer) -> "HipAdamW":
@@ -130,13 +133,56 @@ class HipAdamW(torch.optim.Optimizer):
         self.state = optimizer.state
         for g in self.param_groups:
             g.setdefault("adamw", adamw)
-        self._table, self._plist = None, []
+        self._table, self._plist, self._plan = None, [], None
         return self
 
     def _build(self):
         self._plist = [p for g in self.param_groups for p in g["params"]]
         L.require_cuda(*self._plist[:1])
         self._table = _TensorTable(self._plist)
+
+    def _plan_build(self):
+        """Per-parameter constants of the descriptor table, cached between steps (the table has ~500 rows and filling it
+        row by row in Python cost 4 ms of host time per step).  Everything that can change between steps without the
+        optimizer noticing is re-validated cheaply in step(): gradient / parameter addresses, state identity, shadows."""
+        n = len(self._plist)
+        base = np.zeros(n, dtype=_DESC)
+        gidx = np.zeros(n, dtype=np.int64)
+        steps, states, k0 = [], [], np.zeros(n, dtype=np.float64)
+        i = 0
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if not p.is_contiguous():
+                    raise L.DccError("HIP optimizer expects contiguous parameters")
+                st = self.state.get(p)  # created on the first gradient (step()), like torch.optim.AdamW
+                if st is not None and len(st) == 0:
+                    st = None
+                if st is not None:
+                    if not torch.is_tensor(st["step"]):
+                        st["step"] = torch.tensor(float(st["step"]))
+                    base[i]["m"], base[i]["v"] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                    k0[i] = float(st["step"])
+                base[i]["p"], base[i]["n"] = p.data_ptr(), p.numel()
+                gidx[i] = gi
+                steps.append(st["step"] if st is not None else None)
+                states.append((st, st["exp_avg"], st["exp_avg_sq"]) if st is not None else (None, None, None))
+                i += 1
+        self._plan = dict(base=base, gidx=gidx, steps=steps, states=states, k=k0,
+                          pptr=[p.data_ptr() for p in self._plist])
+
+    def _plan_valid(self) -> bool:
+        pl = self._plan
+        if pl is None or len(pl["pptr"]) != len(self._plist):
+            return False
+        for p, ptr, (st, m, v), stp in zip(self._plist, pl["pptr"], pl["states"], pl["steps"]):
+            cur = self.state.get(p)
+            if cur is not None and len(cur) == 0:
+                cur = None
+            if p.data_ptr() != ptr or cur is not st:
+                return False
+            if st is not None and (st["exp_avg"] is not m or st["exp_avg_sq"] is not v or st["step"] is not stp):
+                return False
+        return True
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: torch.Tensor | None = None, scaled: set | None = None):
@@ -145,35 +191,58 @@ class HipAdamW(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         if self._table is None or len(self._plist) != sum(len(g["params"]) for g in self.param_groups):
             self._build()
-        d = np.zeros(len(self._plist), dtype=_DESC)
+            self._plan = None
+        if not self._plan_valid():
+            self._plan_build()
+        pl = self._plan
+        plist = self._plist
+        gptr = np.fromiter((_grad_ptr(p) if (p.requires_grad and p.grad is not None) else 0 for p in plist), dtype=np.uint64,
+                           count=len(plist))
+        live = gptr != 0
+        fresh = [i for i in np.nonzero(live)[0] if pl["steps"][i] is None]
+        if fresh:  # a parameter got its first gradient: create its state, rebuild the cached rows
+            for i in fresh:
+                p = plist[i]
+                st = self.state[p]
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            self._plan_build()
+            pl = self._plan
+        idx = np.nonzero(live)[0]
+        torch._foreach_add_([pl["steps"][i] for i in idx], 1.0)   # torch's per-parameter step tensors (checkpoint layout)
+        pl["k"][idx] += 1.0
+        d = pl["base"].copy()
+        d["g"] = gptr
+        groups = self.param_groups
+        gi = pl["gidx"]
+        b1 = np.array([g["betas"][0] for g in groups], dtype=np.float64)[gi]
+        b2 = np.array([g["betas"][1] for g in groups], dtype=np.float64)[gi]
+        d["lr"] = np.array([float(g["lr"]) for g in groups], dtype=np.float64)[gi]
+        d["beta1"], d["beta2"] = b1, b2
+        d["eps"] = np.array([g["eps"] for g in groups], dtype=np.float64)[gi]
+        d["wd"] = np.array([g["weight_decay"] for g in groups], dtype=np.float64)[gi]
+        k = np.maximum(pl["k"], 1.0)
+        d["bc1"], d["bc2"] = 1.0 - b1 ** k, 1.0 - b2 ** k
+        adamw = np.array([1 if g.get("adamw", True) else 0 for g in groups], dtype=np.int32)[gi]
+        inclip = np.full(len(plist), 2, dtype=np.int32) if scaled is None else \
+            np.fromiter((2 if id(p) in scaled else 0 for p in plist), dtype=np.int32, count=len(plist))
+        d["flags"] = adamw | inclip
+        # a whole-parameter bf16 shadow (functional.wcast) is refreshed by the update kernel itself
         refreshed: list = []
-        i = 0
-        for g in self.param_groups:
-            b1, b2 = g["betas"]
-            for p in g["params"]:
-                gp = _grad_ptr(p) if p.requires_grad else 0
-                if gp:
-                    st = self.state[p]
-                    if len(st) == 0:
-                        st["step"] = torch.tensor(0.0)
-                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["step"] = st["step"] + 1 if torch.is_tensor(st["step"]) else st["step"] + 1
-                    k = float(st["step"])
-                    # a whole-parameter bf16 shadow (functional.wcast) is refreshed by the update kernel itself
-                    shadow, skey = 0, (0, tuple(p.shape), tuple(p.stride()), torch.bfloat16)
-                    cache = p.__dict__.get("_dcc_shadows")
-                    if cache is not None and skey in cache and p.is_contiguous():
-                        shadow = cache[skey][1].data_ptr()
-                        refreshed.append((p, skey))
-                    flags = (1 if g.get("adamw", True) else 0) | (2 if (scaled is None or id(p) in scaled) else 0)
-                    d[i] = (p.data_ptr(), gp, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), shadow, p.numel(),
-                            float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], 1.0 - b1 ** k, 1.0 - b2 ** k, flags)
-                    if not p.is_contiguous():
-                        raise L.DccError("HIP optimizer expects contiguous parameters")
-                else:
-                    d[i]["n"] = p.numel()
-                i += 1
+        for i in idx:
+            p = plist[i]
+            cache = p.__dict__.get("_dcc_shadows")
+            if cache:
+                skey = (0, tuple(p.shape), tuple(p.stride()), torch.bfloat16)
+                hit = cache.get(skey)
+                if hit is not None:
+                    d[i]["shadow"] = hit[1].data_ptr()
+                    refreshed.append((p, skey))
+        dead = ~live
+        if dead.any():  # rows without a gradient are skipped by the kernel (g == 0)
+            for f in ("p", "m", "v", "shadow"):
+                d[f][dead] = 0
         t = self._table
         t.upload(d)
         L.call("dcc_adam_step", L.ptr(t.dev), L.ptr(t.work), t.nblocks, L.ptr(grad_scale), L.stream())

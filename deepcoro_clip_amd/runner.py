@@ -36,6 +36,50 @@ def _cfg(config, name, default):
     return getattr(config, name, default) if config is not None else default
 
 
+class StepMetrics(dict):
+    """The per-step metric dict (`_train_step`'s first return value, same keys and float values as the reference's),
+    filled on FIRST ACCESS: the scalars travel in one asynchronous device->pinned-host copy and the host only waits for
+    it when a value is actually read.  A loop that looks at the metrics every step (`_run_epoch`, the reference's own
+    loop) behaves exactly as before; a loop that does not (bench.py, log-every-N training) no longer drains the GPU
+    queue once per step, so the next step's launches overlap the current step's backward."""
+
+    def __init__(self, host: torch.Tensor, event, build):
+        super().__init__()
+        self._pending = (host, event, build)
+
+    def _resolve(self):
+        pending, self._pending = self._pending, None
+        if pending is not None:
+            host, event, build = pending
+            event.synchronize()
+            dict.update(self, build(host.tolist()))
+
+    def ready(self) -> bool:
+        """True once the values are on the host (never blocks)."""
+        return self._pending is None or self._pending[1].query()
+
+    def __getitem__(self, k): self._resolve(); return dict.__getitem__(self, k)
+    def __setitem__(self, k, v): self._resolve(); dict.__setitem__(self, k, v)
+    def __delitem__(self, k): self._resolve(); dict.__delitem__(self, k)
+    def __contains__(self, k): self._resolve(); return dict.__contains__(self, k)
+    def __iter__(self): self._resolve(); return dict.__iter__(self)
+    def __len__(self): self._resolve(); return dict.__len__(self)
+    def __repr__(self): self._resolve(); return dict.__repr__(self)
+    def __eq__(self, o): self._resolve(); return dict.__eq__(self, o)
+    def __ne__(self, o): self._resolve(); return dict.__ne__(self, o)
+    def __or__(self, o): self._resolve(); return dict(self) | o
+    def __reduce__(self): self._resolve(); return (dict, (dict(self),))
+    def keys(self): self._resolve(); return dict.keys(self)
+    def values(self): self._resolve(); return dict.values(self)
+    def items(self): self._resolve(); return dict.items(self)
+    def get(self, k, d=None): self._resolve(); return dict.get(self, k, d)
+    def pop(self, *a): self._resolve(); return dict.pop(self, *a)
+    def popitem(self): self._resolve(); return dict.popitem(self)
+    def setdefault(self, k, d=None): self._resolve(); return dict.setdefault(self, k, d)
+    def update(self, *a, **k): self._resolve(); dict.update(self, *a, **k)
+    def copy(self): self._resolve(); return dict(self)
+
+
 @RunnerRegistry.register("DeepCORO_clip")
 @RunnerRegistry.register("DeepCORO_clip_test")
 class VideoContrastiveLearningRunner:
@@ -209,20 +253,30 @@ class VideoContrastiveLearningRunner:
         pack[1:2] = self.log_temp.detach().reshape(-1)[:1]
         if scal is not None:
             pack[2:9] = scal[:7] if scal.numel() >= 7 else 0
-        vals = pack.tolist()  # the one host sync of the step
-        m = {"loss": vals[0], "temperature": math.exp(vals[1]), "contrastive/clip_loss": vals[0]}
-        if scal is not None and text_emb is not None:
-            m["video_norm"] = vals[2 + 5] / B
-            m["text_norm"] = vals[2 + 6] / max(1, text_emb.shape[0])
-        for i, pg in enumerate(self.optimizer.param_groups if self.optimizer is not None else []):
-            m[f"lr/{pg.get('name', str(i))}"] = pg["lr"]
-        if have_align:
-            m["alignment_logprob"] = vals[2 + 3]
-            m["alignment_score"] = math.exp(vals[2 + 3])
-            m["alignment_cosine"] = vals[2 + 4]
-        else:
-            m["alignment_score"] = 0.0
-        return m
+        host = torch.empty(10, dtype=torch.float32, pin_memory=True)
+        host.copy_(pack, non_blocking=True)  # the one device->host transfer of the step; waited for on first read
+        event = torch.cuda.Event()
+        event.record()
+        n_text = text_emb.shape[0] if text_emb is not None else 0
+        lrs = {f"lr/{pg.get('name', str(i))}": pg["lr"]
+               for i, pg in enumerate(self.optimizer.param_groups if self.optimizer is not None else [])}
+        has_scal, has_text = scal is not None, text_emb is not None
+
+        def build(vals):
+            m = {"loss": vals[0], "temperature": math.exp(vals[1]), "contrastive/clip_loss": vals[0]}
+            if has_scal and has_text:
+                m["video_norm"] = vals[2 + 5] / B
+                m["text_norm"] = vals[2 + 6] / max(1, n_text)
+            m.update(lrs)
+            if have_align:
+                m["alignment_logprob"] = vals[2 + 3]
+                m["alignment_score"] = math.exp(vals[2 + 3])
+                m["alignment_cosine"] = vals[2 + 4]
+            else:
+                m["alignment_score"] = 0.0
+            return m
+
+        return StepMetrics(host, event, build)
 
     # --------------------------------------------------------------------------------------- train / val step
     def _train_step(self, videos: torch.Tensor, input_ids: Optional[torch.Tensor] = None,
