@@ -415,6 +415,134 @@ int launch_layout(const GemmParams& p, int a_km, int b_km, dim3 grid, hipStream_
   return dcc_check_launch();
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// fp32 GEMMs with a handful of rows (M <= 32: the study aggregator and projection heads work on [batch, 512] tensors).
+// The tiled kernel runs them on 4 workgroups with a serial, latency-bound K loop (45-160 us each, on the critical
+// path between the towers and the loss).  Here K is spread over the threads of a block instead: every thread issues
+// all its loads up front, keeps an [MT][4] accumulator slab, and the block folds the partials through shuffles + LDS.
+__device__ __forceinline__ float skinny_epilogue(const GemmParams& p, float v, int row, int col) {
+  v = v * p.alpha + ((p.flags & GEMM_BIAS) ? p.bias[col] : 0.0f);
+  if (p.flags & GEMM_SAVE_PRE) reinterpret_cast<float*>(p.aux)[(int64_t)row * p.ldaux + col] = v;
+  if (p.flags & GEMM_GELU) v = gelu_f(v);
+  if (p.flags & GEMM_DGELU) v *= dgelu_f(reinterpret_cast<const float*>(p.aux)[(int64_t)row * p.ldaux + col]);
+  if (p.flags & GEMM_RESID) v += reinterpret_cast<const float*>(p.R)[(int64_t)row * p.ldr + col];
+  return v;
+}
+
+// One step of a halving wave reduction: N values per lane -> N/2, the lanes with bit `o` set keep the upper half.
+// Reducing N values over 64 lanes this way costs ~N shuffles instead of 6 N.
+template <int N, int NMAX>
+__device__ __forceinline__ void fold_step(float (&v)[NMAX], int lane, int o) {
+  const bool up = (lane & o) != 0;
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) {
+    const float send = up ? v[i] : v[i + N / 2];
+    const float keep = up ? v[i + N / 2] : v[i];
+    v[i] = keep + __shfl_xor(send, o);
+  }
+}
+
+// B[n][k] (K contiguous): block = 4 output columns, threads stride over K in float4 steps
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_nt_kernel(GemmParams p) {
+  __shared__ float red[4][MT * 4];
+  const float* A = reinterpret_cast<const float*>(p.A);
+  const float* B = reinterpret_cast<const float*>(p.B);
+  const int n0 = blockIdx.x * 4, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NV = MT * 4;
+  float acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
+  for (int k = tid * 4; k < p.K; k += 1024) {
+    f32x4 b[4], a[MT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const f32x4*>(B + (int64_t)(n0 + c < p.N ? n0 + c : p.N - 1) * p.ldb + k);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(A + (int64_t)(m < p.M ? m : p.M - 1) * p.lda + k);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[m * 4 + c] += a[m][0] * b[c][0] + a[m][1] * b[c][1] + a[m][2] * b[c][2] + a[m][3] * b[c][3];
+  }
+  fold_step<NV, NV>(acc, lane, 32); fold_step<NV / 2, NV>(acc, lane, 16); fold_step<NV / 4, NV>(acc, lane, 8);
+  fold_step<NV / 8, NV>(acc, lane, 4); fold_step<NV / 16, NV>(acc, lane, 2);
+  {
+    const int base = ((lane >> 5) & 1) * (NV / 2) + ((lane >> 4) & 1) * (NV / 4) + ((lane >> 3) & 1) * (NV / 8) +
+                     ((lane >> 2) & 1) * (NV / 16) + ((lane >> 1) & 1) * (NV / 32);
+#pragma unroll
+    for (int i = 0; i < NV / 32; ++i) {
+      const float v = acc[i] + __shfl_xor(acc[i], 1);
+      if (!(lane & 1)) red[wave][base + i] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < MT * 4) {
+    const int m = tid >> 2, c = tid & 3, col = n0 + c;
+    if (m < p.M && col < p.N) {
+      const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+      reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + col] = skinny_epilogue(p, v, m, col);
+    }
+  }
+}
+
+// B[k][n] (N contiguous): block = 16 output columns (4 float4 lanes) x 64 K slices
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_nn_kernel(GemmParams p) {
+  __shared__ float red[4][4][MT * 4];  // [wave][quad][m*4+e]
+  const float* A = reinterpret_cast<const float*>(p.A);
+  const float* B = reinterpret_cast<const float*>(p.B);
+  const int tid = threadIdx.x, q = tid & 3, s = tid >> 2, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16 + 4 * q;
+  const int ks = ((p.K + 63) / 64 + 3) & ~3;  // K slice per thread, a multiple of 4 (A is read in float4 steps)
+  const int kb = s * ks;
+  constexpr int NV = MT * 4;
+  float acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
+  const bool ncol = n0 < p.N;  // N % 4 == 0: a quad is either fully inside or outside
+  for (int k = kb; k < kb + ks && k < p.K; k += 4) {
+    f32x4 b[4], a[MT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(B + (int64_t)(k + j < p.K ? k + j : p.K - 1) * p.ldb + (ncol ? n0 : 0));
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(A + (int64_t)(m < p.M ? m : p.M - 1) * p.lda + k);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float av = (k + j < p.K) ? a[m][j] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m * 4 + c] += av * b[j][c];
+      }
+  }
+  // fold the 16 K slices of a wave (lanes with equal q) by halving, then the 4 waves through LDS
+  fold_step<NV, NV>(acc, lane, 32); fold_step<NV / 2, NV>(acc, lane, 16); fold_step<NV / 4, NV>(acc, lane, 8);
+  fold_step<NV / 8, NV>(acc, lane, 4);
+  {
+    const int base = ((lane >> 5) & 1) * (NV / 2) + ((lane >> 4) & 1) * (NV / 4) + ((lane >> 3) & 1) * (NV / 8) +
+                     ((lane >> 2) & 1) * (NV / 16);
+#pragma unroll
+    for (int i = 0; i < NV / 16; ++i) red[wave][q][base + i] = acc[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < 4 * MT * 4; i += 256) {
+    const int qq = i / (MT * 4), r = i - qq * (MT * 4), m = r >> 2, c = r & 3;
+    const int col = blockIdx.x * 16 + 4 * qq + c;
+    if (m < p.M && col < p.N) {
+      const float v = red[0][qq][r] + red[1][qq][r] + red[2][qq][r] + red[3][qq][r];
+      reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + col] = skinny_epilogue(p, v, m, col);
+    }
+  }
+}
+
+template <int MT>
+int launch_skinny(const GemmParams& p, int b_km, hipStream_t st) {
+  if (b_km) hipLaunchKernelGGL((gemm_skinny_nn_kernel<MT>), dim3((p.N + 15) / 16), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_skinny_nt_kernel<MT>), dim3((p.N + 3) / 4), dim3(256), 0, st, p);
+  return dcc_check_launch();
+}
+
 }  // namespace
 
 // See include/dcc.h for the contract.
@@ -447,12 +575,22 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   GemmParams p{A, B, C, bias, R, aux, colsum, lda, ldb, ldc, ldr, ldaux, sA, sB, sC, M, N, K, batch, splitk, alpha, (flags & 0xff) | (((flags >> 8) & 0xff) == 4 ? 0x1000 : 0)};
   if ((int64_t)batch * splitk > 65535) return DCC_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == DCC_F32 && out_dtype == DCC_F32 && aligned && !a_km && M <= 32 && batch == 1 && splitk == 1 && K >= 64 &&
+      !(flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && ((flags >> 8) & 0xff) != 3) {  // a handful of rows: K spread over threads
+    if (M <= 8) return launch_skinny<8>(p, b_km, st);
+    if (M <= 16) return launch_skinny<16>(p, b_km, st);
+    if (M <= 24) return launch_skinny<24>(p, b_km, st);
+    return launch_skinny<32>(p, b_km, st);
+  }
   // tile choice: 128x128 unless that leaves most of the 256 CUs idle
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch * splitk;
   const int variant = (flags >> 8) & 0xff;  // tuning knob (bench / tests only): 1 = BK 32 for the 128-tile bf16 kernels, 2 = 64x64 tiles, 3 = no ring kernel
   const bool small = in_dtype == DCC_BF16 && (t128 < 192 || variant == 2);
   const int bmn = small ? 64 : 128;
-  if (in_dtype == DCC_BF16 && aligned && !small && variant != 3) {  // the towers' large GEMMs: persistent LDS-DMA ring kernel
+  // persistent LDS-DMA ring kernel: the towers' large GEMMs, and (measured, scratch/gemm_small.py) also the small grids
+  // of the text tower and the deep-K rel-pos table gradients, where its 3-4 stage pipeline hides the per-step load
+  // latency the tiled kernel exposes (variant 6 restores the tiled kernel for small grids)
+  if (in_dtype == DCC_BF16 && aligned && variant != 3 && variant != 2 && !(small && variant == 6)) {
     const int rc = dcc_gemm_ring_launch(p, a_km, b_km, out_dtype, st);
     if (rc != DCC_ERR_UNSUPPORTED) return rc;
   }

@@ -43,8 +43,20 @@ class _TensorTable:
         self.events = [None, None]
         self.turn = 0
         self.dev = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        # staging buffer of a captured step (HIP graph): the copy node re-reads it at every replay, so a replay driver
+        # rewrites it (refill) after the previous replay has finished and before the next launch
+        self.cap_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+        self.captured = False
+
+    def refill(self, desc: np.ndarray):
+        self.cap_host.numpy().view(_DESC)[:] = desc
 
     def upload(self, desc: np.ndarray):
+        if torch.cuda.is_current_stream_capturing():
+            self.refill(desc)
+            self.dev.copy_(self.cap_host, non_blocking=True)
+            self.captured = True
+            return
         i = self.turn
         self.turn ^= 1
         if self.events[i] is not None:

@@ -110,7 +110,7 @@ class VideoContrastiveLearningRunner:
         self.log_temp = log_temp
         self.step = 0
         self.scheduler_per_iteration = self._scheduler_is_per_iteration()
-        self.initial_log_temp = log_temp.clone() if log_temp is not None else torch.log(torch.tensor(config.temperature))
+        self.initial_log_temp = log_temp.detach().clone() if log_temp is not None else torch.log(torch.tensor(config.temperature))
         self.use_weighted_siglip = bool(_cfg(config, "siglip_use_weighted_loss", False))
         self.weighted_siglip_loss = WeightedSigLIPLoss() if self.use_weighted_siglip else None
         self.siglip_abnormal_margin = float(_cfg(config, "siglip_abnormal_margin", 0.0))
@@ -187,7 +187,8 @@ class VideoContrastiveLearningRunner:
             with torch.cuda.stream(self._text_stream):
                 text_emb = self.text_encoder(input_ids, attention_mask)
             main.wait_stream(self._text_stream)
-            text_emb.record_stream(main)
+            if not torch.cuda.is_current_stream_capturing():
+                text_emb.record_stream(main)
         else:
             video_emb = self.video_encoder(videos)
         # torch.nan_to_num(emb, nan=0, posinf=1e4, neginf=-1e4): applied in place on the embedding storage (finite
@@ -253,10 +254,17 @@ class VideoContrastiveLearningRunner:
         pack[1:2] = self.log_temp.detach().reshape(-1)[:1]
         if scal is not None:
             pack[2:9] = scal[:7] if scal.numel() >= 7 else 0
-        host = torch.empty(10, dtype=torch.float32, pin_memory=True)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:  # captured step: the copy node writes this fixed buffer at every replay (see StepGraph)
+            if getattr(self, "_graph_host", None) is None:
+                raise RuntimeError("graph capture needs runner._graph_host (use StepGraph)")
+            host = self._graph_host
+        else:
+            host = torch.empty(10, dtype=torch.float32, pin_memory=True)
         host.copy_(pack, non_blocking=True)  # the one device->host transfer of the step; waited for on first read
         event = torch.cuda.Event()
-        event.record()
+        if not capturing:
+            event.record()
         n_text = text_emb.shape[0] if text_emb is not None else 0
         lrs = {f"lr/{pg.get('name', str(i))}": pg["lr"]
                for i, pg in enumerate(self.optimizer.param_groups if self.optimizer is not None else [])}

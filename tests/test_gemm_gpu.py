@@ -202,3 +202,39 @@ def test_ring_batched_and_matches_staged_kernel():
     finally:
         Kx.GEMM_VARIANT = old
     assert torch.equal(o_ring, o_staged)
+
+
+@pytest.mark.parametrize("b_km", [False, True])
+@pytest.mark.parametrize("M,N,K", [(1, 8, 64), (7, 24, 100), (24, 512, 2048), (24, 2048, 512), (24, 24, 512), (32, 520, 1536),
+                                   (17, 1536, 512)])
+def test_gemm_skinny_fp32_rows(b_km, M, N, K):
+    """fp32 GEMMs with a handful of rows (aggregator / projection heads on [batch, 512]) take the K-over-threads kernel:
+    exact on integer data, every epilogue against the torch expression."""
+    from deepcoro_clip_amd import kernels as Kx
+
+    g = torch.Generator(device="cpu").manual_seed(M * 13 + N + K)
+    ai = torch.randint(-3, 4, (M, K), generator=g).float().cuda()
+    bi = torch.randint(-3, 4, (K, N) if b_km else (N, K), generator=g).float().cuda()
+    outi = Kx.gemm(ai, bi, b_km=b_km)
+    assert torch.equal(outi.double(), _ref(ai, bi, False, b_km)), "exact integer data"
+    a = torch.randn(M, K, generator=g).cuda()
+    b = (torch.randn((K, N) if b_km else (N, K), generator=g) * 0.05).cuda()
+    bias, resid = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    pre = a.double() @ (b.double() if b_km else b.double().t()) + bias.double()
+    aux = torch.empty(M, N, device="cuda")
+    out = Kx.gemm(a, b, b_km=b_km, bias=bias, gelu=True, save_pre=True, aux=aux)
+    assert (aux.double() - pre).abs().max() < 1e-4
+    assert (out.double() - torch.nn.functional.gelu(pre)).abs().max() < 1e-4
+    out = Kx.gemm(a, b, b_km=b_km, bias=bias, resid=resid)
+    assert (out.double() - (pre + resid.double())).abs().max() < 1e-4
+    x = torch.randn(M, N, generator=g).cuda().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    out = Kx.gemm(a, b, b_km=b_km, dgelu=True, aux=x.detach())
+    assert (out.double() - (pre - bias.double()) * x.grad.double()).abs().max() < 1e-4
+    # same numbers as the tiled kernel (variant 3 switches the skinny path off)
+    Kx.GEMM_VARIANT, keep = 3 << 8, Kx.GEMM_VARIANT
+    try:
+        tiled = Kx.gemm(a, b, b_km=b_km, bias=bias, resid=resid)
+    finally:
+        Kx.GEMM_VARIANT = keep
+    assert (tiled - Kx.gemm(a, b, b_km=b_km, bias=bias, resid=resid)).abs().max() < 1e-4
