@@ -42,6 +42,37 @@ def test_layernorm_fwd_bwd(rows, C, dtype, tol):
     assert _rel(gam.grad, gr.grad) < tol and _rel(bet.grad, br.grad) < tol
 
 
+@pytest.mark.parametrize("rows,C", [(5, 96), (4099, 96), (1000, 384), (70000, 96)])
+def test_layernorm_bwd_workspace_and_atomic_paths_agree(rows, C):
+    """dcc_layernorm_bwd folds dgamma/dbeta either through block partials in a caller workspace (+ fold kernel) or, with a
+    null workspace, through atomics; both accumulate INTO the gradients and must agree; a ragged last row group and
+    strided rows (ldx > C) go through the zero-filling buffer loads."""
+    from deepcoro_clip_amd import _lib as L, kernels as K
+
+    g = _gen(rows)
+    ld = C + 32
+    xb = torch.randn(rows, ld, generator=g).cuda().bfloat16()
+    x = xb[:, :C]
+    dy = torch.randn(rows, C, generator=g).cuda().bfloat16()
+    gam, bet = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    _, mean, rstd = K.layernorm_fwd(x, gam, bet, 1e-6)
+    outs = []
+    for use_ws in (True, False):
+        dg, db = torch.full((C,), 0.5, device="cuda"), torch.full((C,), -0.25, device="cuda")
+        dx = torch.empty(rows, C, device="cuda", dtype=torch.bfloat16)
+        ws = torch.empty(1 << 20, device="cuda") if use_ws else None
+        L.call("dcc_layernorm_bwd", L.ptr(dy), C, L.ptr(x), ld, L.ptr(mean), L.ptr(rstd), L.ptr(gam), L.ptr(dx), C, L.ptr(dg),
+               L.ptr(db), None, L.ptr(ws), rows, C, L.dt(x), L.dt(dy), L.stream())
+        outs.append((dx.float(), dg, db))
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    F.layer_norm(xr, (C,), gr, br, 1e-6).backward(dy.float())
+    for dx, dg, db in outs:
+        assert _rel(dx, xr.grad) < 1.5e-2
+        assert _rel(dg - 0.5, gr.grad) < 2e-3 and _rel(db + 0.25, br.grad) < 2e-3
+    assert torch.equal(outs[0][0], outs[1][0])
+
+
 def test_layernorm_rejects_unsupported_width():
     from deepcoro_clip_amd import kernels as K
     from deepcoro_clip_amd._lib import DccError

@@ -205,3 +205,26 @@ def test_baseline_config0_geometry_steps():
         m, emb = runner._train_step(videos=videos.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda())
         assert abs(m["loss"] - ref.item()) < 1e-4 * max(1.0, abs(ref.item())), (step, m["loss"], ref.item())
     assert emb["video_embeddings"].shape == (B, 512)
+
+
+def test_step_metrics_resolve_lazily_with_reference_keys():
+    """`_train_step` returns the reference's metric dict (same keys, float values), filled on first access."""
+    import json
+
+    import __graft_entry__ as ge
+    from deepcoro_clip_amd.runner import StepMetrics
+
+    runner, _, (videos, ids, mask) = ge.make_tiny_setup(torch.float32)
+    m, emb = runner._train_step(videos=videos.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda())
+    assert isinstance(m, dict) and isinstance(m, StepMetrics)
+    torch.cuda.synchronize()
+    assert m.ready()
+    keys = set(m)
+    assert {"loss", "temperature", "contrastive/clip_loss", "video_norm", "text_norm", "alignment_score", "alignment_logprob",
+            "alignment_cosine", "lr/video_backbone", "lr/text_encoder", "lr/temperature"} <= keys
+    assert all(isinstance(v, float) for v in m.values())
+    assert m["loss"] == m["contrastive/clip_loss"] and math.isfinite(m["loss"])
+    plain = dict(m)
+    assert plain == m and {**m} == plain and json.loads(json.dumps(m)) == plain and m.copy() == plain
+    assert m.get("nope", 7) == 7 and "loss" in m and len(m) == len(plain)
+    assert emb["video_embeddings"].shape == (2, 512) and emb["text_embeddings"].shape == (2, 512)
