@@ -46,6 +46,41 @@ def wcast(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return t
 
 
+def stacked_tables(tables, rows: int, width: int, dtype: torch.dtype) -> torch.Tensor:
+    """The rel-pos tables stacked row-wise in the compute dtype, zero padded to `rows`.
+
+    When the tables are bf16-shadowed fp32 Parameters the stack is a persistent buffer whose row slices ARE the
+    parameters' shadows (same cache `wcast` uses): the AdamW kernel rewrites them in its update pass, so a training step
+    spends no cast / fill launches on them (4 per block before).  Anything else (fp32 compute, resampled tables that are
+    autograd intermediates) is cast on the spot."""
+    if dtype != torch.float32 and all(isinstance(t, torch.nn.Parameter) and t.is_contiguous() for t in tables):
+        owner = tables[0]
+        hit = owner.__dict__.get("_dcc_rcat")
+        if hit is None or hit[0] != (rows, width, dtype, tuple(id(t) for t in tables)) or hit[1].device != owner.device:
+            buf = torch.zeros((rows, width), device=owner.device, dtype=dtype)
+            hit = ((rows, width, dtype, tuple(id(t) for t in tables)), buf)
+            owner.__dict__["_dcc_rcat"] = hit
+        buf = hit[1]
+        o = 0
+        for t in tables:
+            cache = t.__dict__.setdefault("_dcc_shadows", {})
+            key = (0, tuple(t.shape), tuple(t.stride()), dtype)
+            stamp = (t._version, _WEPOCH, t.data_ptr())
+            view = buf[o:o + t.shape[0]]
+            ent = cache.get(key)
+            if ent is None or ent[0] != stamp or ent[1].data_ptr() != view.data_ptr():
+                K.cast(t.detach(), dtype, out=view)
+                cache[key] = (stamp, view)
+            o += t.shape[0]
+        return buf
+    out = torch.zeros((rows, width), device=tables[0].device, dtype=dtype)
+    o = 0
+    for t in tables:
+        K.cast(t.detach().contiguous(), dtype, out=out[o:o + t.shape[0]])
+        o += t.shape[0]
+    return out
+
+
 class ZeroArena:
     """One big pre-zeroed fp32 buffer per training step for every gradient that is produced by accumulation
     (split-K / atomics): one memset instead of ~800 small fill launches.  `begin()` re-zeroes and rewinds; slices
@@ -363,11 +398,7 @@ class MvitAttnCoreFn(torch.autograd.Function):
         # rel-pos inner products: ONE GEMM of the (rotated) queries against the three tables stacked
         lens = (rel_h.shape[0], rel_w.shape[0], rel_t.shape[0])
         Lp = 8 * ((sum(lens) + 7) // 8)
-        Rcat = torch.zeros((Lp, D), device=qkv.device, dtype=dt)
-        o = 0
-        for r in (rel_h, rel_w, rel_t):
-            K.cast(r.detach().contiguous(), dt, out=Rcat[o:o + r.shape[0]])
-            o += r.shape[0]
+        Rcat = stacked_tables((rel_h, rel_w, rel_t), Lp, D, dt)
         q2d = Qf.view(-1, DQK)[:, :D]
         P = K.gemm(q2d, Rcat)
         dims_q = K.relpos_dims(B, H, D, A, Lp, q_thw, k_thw, lens)
