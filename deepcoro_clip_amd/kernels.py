@@ -562,6 +562,17 @@ def retrieval_ranks(sim: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     return ranks
 
 
+def topk_rows(sim: torch.Tensor, k: int):
+    """torch.topk(sim, k, dim=1) for fp32 [rows, M]: (values fp32 [rows, k], indices int64 [rows, k]), ties by column."""
+    L.require_cuda(sim)
+    assert sim.dim() == 2 and sim.dtype == torch.float32 and sim.stride(1) == 1 and 1 <= k <= sim.shape[1]
+    idx = torch.empty((sim.shape[0], k), device=sim.device, dtype=torch.int64)
+    val = torch.empty((sim.shape[0], k), device=sim.device, dtype=torch.float32)
+    if sim.shape[0]:
+        L.call("dcc_topk_rows", L.ptr(sim), sim.stride(0), sim.shape[0], sim.shape[1], int(k), L.ptr(idx), L.ptr(val), L.stream())
+    return val, idx
+
+
 # ----------------------------------------------------------------------------------------- loss
 def l2norm_fwd(x: torch.Tensor, eps: float = 1e-12, norm_sum: torch.Tensor | None = None):
     L.require_cuda(x, norm_sum)

@@ -399,10 +399,12 @@ class VideoContrastiveLearningRunner:
         sums: Dict[str, float] = {}
         count = 0
         all_v, all_t = [], []
+        all_texts: List[List[str]] = []   # positive texts per validation video (reference :768-802)
+        all_paths: List[str] = []
         for batch in loader:
             if batch is None or batch.get("videos") is None:
                 continue
-            step_inputs, _paths = self._preprocess_inputs(batch)
+            step_inputs, paths = self._preprocess_inputs(batch)
             metrics, emb = (self._train_step if training else self._val_step)(**step_inputs)
             if not math.isfinite(metrics["loss"]):
                 raise RuntimeError(f"NaN loss encountered in {mode} at step {self.step} (epoch {epoch})")
@@ -411,19 +413,110 @@ class VideoContrastiveLearningRunner:
             count += 1
             all_v.append(emb["video_embeddings"])
             all_t.append(emb["text_embeddings"])
+            if not training:
+                rows = emb["video_embeddings"].shape[0]
+                texts = self._batch_positive_texts(batch, rows)
+                all_texts.extend(texts)
+                plist = list(paths) if paths else []
+                all_paths.extend(plist + [""] * (rows - len(plist)))
         out = {f"{mode}/{k}": v / max(count, 1) for k, v in sums.items()}
         if not training and all_v:
             v = self._gather_tensor_along_batch(torch.cat(all_v, 0), self.world_size)
-            t = self._gather_tensor_along_batch(torch.cat(all_t, 0), self.world_size)
-            if _cfg(self.config, "is_ref_device", True) and t.numel() and t.shape[0] == v.shape[0]:
-                sim = compute_similarity_matrix(v, t)
-                gt = torch.arange(v.shape[0])
-                out.update({f"{mode}/{k}": x for k, x in compute_recall_at_k(sim, gt, self.config.recall_k).items()})
-                out.update({f"{mode}/{k}": x for k, x in compute_mrr(sim, gt).items()})
-                out[f"{mode}/MAP"] = compute_map(sim, gt)
-                out[f"{mode}/MedianRank_V2T"] = compute_median_rank(sim, gt)
-                out.update({f"{mode}/{k}": x for k, x in compute_ndcg_at_k(sim, gt, self.config.ndcg_k).items()})
+            texts = self._gather_objects(all_texts)
+            paths_g = self._gather_objects(all_paths)
+            tok = getattr(self.text_encoder.module if hasattr(self.text_encoder, "module") else self.text_encoder,
+                          "tokenizer", None)
+            if _cfg(self.config, "is_ref_device", True):
+                if tok is not None and len(texts) == v.shape[0] and any(t for t in texts):
+                    out.update({f"{mode}/{k}": x for k, x in self._unique_text_retrieval(v, texts, paths_g, tok, epoch).items()})
+                else:  # no report texts / no tokenizer: the in-batch pairs are the ground truth (diagonal)
+                    t = self._gather_tensor_along_batch(torch.cat(all_t, 0), self.world_size)
+                    if t.numel() and t.shape[0] == v.shape[0]:
+                        out.update({f"{mode}/{k}": x for k, x in
+                                    self._retrieval_metrics(compute_similarity_matrix(v, t), torch.arange(v.shape[0])).items()})
         return self._maybe_reduce_metrics(out)
+
+    # ------------------------------------------------------------------------- epoch-end retrieval (val)
+    @staticmethod
+    def _batch_positive_texts(batch: dict, rows: int) -> List[List[str]]:
+        """Positive prompts of every video of a batch: the active columns of `positive_mask` mapped through
+        `text_metadata[*]['prompt_text']`, else the sample's own report (reference :772-800)."""
+        reports = list(batch.get("reports", []) or [])
+        mask, meta = batch.get("positive_mask"), batch.get("text_metadata")
+        out: List[List[str]] = []
+        if isinstance(mask, torch.Tensor) and isinstance(meta, list) and mask.numel() > 0:
+            m = mask.detach().cpu()
+            for r in range(m.size(0)):
+                prompts = [meta[c].get("prompt_text", "") for c in (m[r] > 0).nonzero(as_tuple=False).flatten().tolist()
+                           if c < len(meta)]
+                prompts = [p for p in prompts if p]
+                if not prompts and r < len(reports) and reports[r]:
+                    prompts = [reports[r]]
+                out.append(prompts)
+        else:
+            out = [[t] if t else [] for t in reports]
+        out.extend([] for _ in range(rows - len(out)))
+        return out[:rows] if rows else out
+
+    def _gather_objects(self, local: list) -> list:
+        if self.world_size <= 1 or not (dist.is_available() and dist.is_initialized()):
+            return local
+        parts: list = [None] * self.world_size
+        dist.all_gather_object(parts, local)
+        return [x for p in parts for x in p]
+
+    def _retrieval_metrics(self, sim: torch.Tensor, gt) -> dict:
+        out = dict(compute_recall_at_k(sim, gt, self.config.recall_k))
+        out.update(compute_mrr(sim, gt))
+        out.update(compute_ndcg_at_k(sim, gt, self.config.ndcg_k))
+        out["MAP"] = compute_map(sim, gt)
+        out["MedianRank_V2T"] = compute_median_rank(sim, gt)
+        return out
+
+    def _unique_text_retrieval(self, video_feats: torch.Tensor, positive_texts: List[List[str]], paths: List[str], tokenizer,
+                               epoch: int) -> dict:
+        """Epoch-end validation retrieval (reference :853-1021): de-duplicate the positive texts, re-encode the unique
+        ones in batches of 64 with the text tower, score every video against every unique text ([Nv, Mt] cosine
+        similarities on the GPU) and rank the ground-truth index SETS (rank kernel: retrieval_metrics.gt_ranks)."""
+        unique = sorted({t for ts in positive_texts for t in ts if t}) or [""]
+        index = {t: i for i, t in enumerate(unique)}
+        gt_sets: List[List[int]] = []
+        for vid, ts in enumerate(positive_texts):
+            ids: List[int] = []
+            for t in ts:
+                j = index.get(t)
+                if j is not None and j not in ids:
+                    ids.append(j)
+            if not ids:
+                fallback = ts[0] if ts else ""
+                if fallback not in index:
+                    raise ValueError(f"Missing ground-truth text in mapping: '{fallback}' for identifier '{paths[vid] if vid < len(paths) else vid}'")
+                ids.append(index[fallback])
+            gt_sets.append(ids)
+        enc = self.text_encoder
+        was_training = enc.training
+        enc.eval()
+        embs = []
+        with torch.no_grad():
+            for s0 in range(0, len(unique), 64):
+                tk = tokenizer(unique[s0:s0 + 64], padding=True, truncation=True, return_tensors="pt")
+                e = enc(tk["input_ids"].to(self.device), tk["attention_mask"].to(self.device))
+                e = K.nan_to_num_(e.float().contiguous(), 0.0, 1e4, -1e4)
+                embs.append(e)
+        enc.train(was_training)
+        bank = torch.cat(embs, 0)
+        sim = compute_similarity_matrix(video_feats, bank)   # L2-normalises both sides (reference steps 4-5)
+        out = self._retrieval_metrics(sim, gt_sets)
+        if self.output_dir:
+            import csv
+            os.makedirs(self.output_dir, exist_ok=True)
+            with open(os.path.join(self.output_dir, "val_unique_texts.csv"), "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(["Index", "Text"])
+                w.writerows(enumerate(unique))
+            torch.save({"text_embeddings": bank.cpu(), "text_to_index": index, "unique_texts": unique},
+                       os.path.join(self.output_dir, f"val_text_embeddings_epoch_{epoch}.pt"))
+        return out
 
     def train(self, start_epoch: int, end_epoch: int) -> None:
         for epoch in range(start_epoch, end_epoch):
@@ -482,7 +575,7 @@ class VideoContrastiveLearningRunner:
             for batch in self.val_loader:
                 v = self.video_encoder(batch["videos"].to(self.device).float())
                 sim = compute_similarity_matrix(v, bank)
-                results.append(torch.topk(sim, k=min(topk, bank.shape[0]), dim=1)[1].cpu())
+                results.append(K.topk_rows(sim.float().contiguous(), min(topk, bank.shape[0]))[1].cpu())
         return torch.cat(results, 0) if results else torch.empty(0, dtype=torch.long)
 
 

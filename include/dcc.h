@@ -184,6 +184,10 @@ int dcc_adam_step(const void* tab, const void* work, int nblocks, const float* g
  * these integers.  gt int32 [Nq, G], -1 = empty; ranks int32 [Nq, G], 1-based, 0 for empty slots. */
 int dcc_retrieval_ranks(const float* sim, int64_t ld, const int* gt, int* ranks, int Nq, int Nc, int G, void* stream);
 
+/* ---- inference() top-k (csrc/misc.hip): torch.topk(sim, k, dim=1) of runners/video_constrative_learning_runner.py:1731-1758.
+ * idx int64 [rows, k], val fp32 [rows, k]: the first k entries of a stable descending sort of each row (NaN first). */
+int dcc_topk_rows(const float* sim, int64_t ld, int rows, int M, int k, int64_t* idx, float* val, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 """Epoch-end retrieval metrics on the GPU (dcc_retrieval_ranks + host arithmetic) against the values produced by the
 reference's utils/retrieval_metrics.py (tests/golden/retrieval.npz) and against the CPU oracle; ranks are integers,
 so parity is exact."""
+import math
 import os
 
 import numpy as np
@@ -86,3 +87,76 @@ def test_metrics_match_oracle_multi_positive_and_edge_cases():
     assert RM.compute_ndcg_at_k(sim, gt, [1, 5]) == pytest.approx(OM.ndcg_at_k(simn, gt, [1, 5]), abs=1e-6)
     one = torch.randn(6, 1).cuda()
     assert RM.compute_mrr(one, torch.zeros(6, dtype=torch.long))["MRR_V2T"] == 1.0  # reference: single text -> 1.0
+
+
+@pytest.mark.parametrize("rows,M,k", [(1, 1, 1), (7, 5, 5), (24, 1000, 5), (3, 40000, 10), (64, 257, 32)])
+def test_topk_rows_is_the_head_of_a_stable_descending_sort(rows, M, k):
+    """inference()'s torch.topk (runner :1731-1758): values descending, ties by column, NaN first; exact."""
+    from deepcoro_clip_amd import kernels as K
+
+    g = torch.Generator().manual_seed(rows * 31 + M)
+    for sim in (torch.randn(rows, M, generator=g), torch.randint(-3, 4, (rows, M), generator=g).float() * 0.5):
+        if M > 3:
+            sim[0, 2] = float("inf"); sim[0, 1] = float("-inf"); sim[rows - 1, M - 1] = float("nan")
+        wide = torch.zeros(rows, M + 3)
+        wide[:, :M] = sim
+        val, idx = K.topk_rows(wide.cuda()[:, :M], k)
+        key = torch.where(torch.isnan(sim), torch.full_like(sim, float("inf")), sim).double() + torch.isnan(sim).double()
+        ref = torch.sort(key, dim=1, descending=True, stable=True)[1][:, :k]   # NaN above +inf, ties by column
+        assert torch.equal(idx.cpu(), ref)
+        got, want = val.cpu(), torch.gather(sim, 1, ref)
+        assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(got[~torch.isnan(got)], want[~torch.isnan(want)])
+        if not torch.isnan(sim).any() and sim.unique().numel() == sim.numel():
+            assert torch.equal(idx.cpu(), torch.topk(sim, k, dim=1)[1])
+
+
+class _ToyTokenizer:
+    """word -> id hashing with padding/truncation, the HF call signature the runner uses."""
+
+    def __call__(self, texts, padding=True, truncation=True, return_tensors="pt"):
+        rows = [[2] + [3 + (sum(map(ord, w)) % 500) for w in t.split()][:14] + [1] for t in texts]
+        n = max(len(r) for r in rows)
+        ids = torch.tensor([r + [0] * (n - len(r)) for r in rows])
+        return {"input_ids": ids, "attention_mask": (ids != 0).long()}
+
+
+def test_val_epoch_reencodes_unique_texts_and_ranks_index_sets(tmp_path):
+    """`_run_epoch('val')` follows the reference's epoch end (runner :853-1021): de-duplicated positive texts re-encoded by
+    the text tower, [Nv, Mt] similarities, ground-truth index SETS; checked against the CPU oracle's metric functions on
+    the same embeddings."""
+    import __graft_entry__ as ge
+    from oracle import metrics as OM
+
+    runner, _, (videos, ids, mask) = ge.make_tiny_setup(torch.float32, B=2)
+    tok = _ToyTokenizer()
+    runner.text_encoder.tokenizer = tok
+    runner.output_dir = str(tmp_path)
+    reports = [["normal coronary arteries", "severe stenosis of the lad"], ["severe stenosis of the lad", "mild disease rca"],
+               ["normal coronary arteries", "occluded graft"]]
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for rep in reports:
+        batches.append({"videos": torch.randn(2, *videos.shape[1:], generator=g), "encoded_texts": tok(rep), "reports": rep,
+                        "paths": [f"clip{len(batches)}a.mp4", f"clip{len(batches)}b.mp4"]})
+    runner.val_loader = batches
+    out = runner._run_epoch("val", 0)
+    uniq = sorted({t for rep in reports for t in rep})
+    assert len(uniq) == 4 and os.path.exists(tmp_path / "val_unique_texts.csv")
+    saved = torch.load(tmp_path / "val_text_embeddings_epoch_0.pt")
+    assert saved["unique_texts"] == uniq and saved["text_embeddings"].shape == (len(uniq), 512)
+    # expected: same video embeddings (eval mode), bank = the saved text embeddings, the oracle's metric functions
+    runner.video_encoder.eval()
+    with torch.no_grad():
+        v = torch.cat([runner.video_encoder(b["videos"].cuda()).float().cpu() for b in batches])
+    sim = torch.nn.functional.normalize(v, dim=1) @ torch.nn.functional.normalize(saved["text_embeddings"], dim=1).t()
+    gt = [[saved["text_to_index"][t]] for rep in reports for t in rep]
+    exp = dict(OM.recall_at_k(sim, gt, [1, 5]))
+    exp.update(OM.mrr(sim, gt)); exp.update(OM.ndcg_at_k(sim, gt, [5]))
+    exp["MAP"] = OM.mean_ap(sim, gt); exp["MedianRank_V2T"] = OM.median_rank(sim, gt)
+    for k_, v_ in exp.items():
+        assert abs(out[f"val/{k_}"] - float(v_)) < 1e-9, (k_, out[f"val/{k_}"], v_)
+    assert math.isfinite(out["val/loss"])
+    # a video whose report is missing from the text set is an error, as in the reference (:877-884)
+    batches[0]["reports"] = ["", "severe stenosis of the lad"]
+    with pytest.raises(ValueError):
+        runner._run_epoch("val", 0)
