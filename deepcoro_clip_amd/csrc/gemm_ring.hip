@@ -405,6 +405,7 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave >> 2;  // 0 consumers, 1 loaders, 2 storers
+  PROF_DECL;
   const int w4 = wave & 3;
   const int G = gridDim.x, bid = blockIdx.x;
   const int item0 = (bid & 7) * (G >> 3) + (bid >> 3);
@@ -482,13 +483,18 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
 #pragma unroll
     for (int d = 0; d < D; ++d) issue();
     for (int q = 0; q < S + 2; ++q) {
+      const unsigned long long t0 = PROF_T();
       if (q < S) {
         if (issued - (q + 1) >= D - 1) wait_vm<(D - 1) * (2 * PPL + 1)>();
         else wait_vm<0>();
       }
+      const unsigned long long t1 = PROF_T();
       __builtin_amdgcn_s_barrier();
+      const unsigned long long t2 = PROF_T();
       if (q < S) issue();
+      PROF_ADD(4, t1 - t0); PROF_ADD(5, t2 - t1); PROF_ADD(6, PROF_T() - t2);
     }
+    PROF_FLUSH();
     return;
   }
 
@@ -509,7 +515,10 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
     bool pending = false;
     int kt = 0;
     for (int q = 0; q < S + 2; ++q) {
+      const unsigned long long tb0 = PROF_T();
       __builtin_amdgcn_s_barrier();
+      const unsigned long long tb1 = PROF_T();
+      PROF_ADD(0, tb1 - tb0); PROF_ADD(3, 1);
       if (pending) {
         // tile finished one step ago: alpha * acc + bias -> bf16 -> mailbox (row m, 4 consecutive columns per write)
 #pragma unroll
@@ -527,8 +536,10 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
           }
         zero_acc();
         pending = false;
+        PROF_ADD(2, PROF_T() - tb1);
       }
       if (q >= S) continue;
+      const unsigned long long tb2 = PROF_T();
       const char* sa = smem + (q % NS) * STAGE_B;
       const char* sb = sa + TILE_B;
       bf16x8 fa[2][2], fb[2][2];
@@ -559,7 +570,9 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) bias4[j][g4] = *reinterpret_cast<const f32x4*>(biasl + wc * 64 + 32 * j + 8 * g4 + 4 * h);
       }
+      PROF_ADD(1, PROF_T() - tb2);
     }
+    PROF_FLUSH();
     return;
   }
 
@@ -577,7 +590,9 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
     const int64_t ldxx = (p.flags & GEMM_RESID) ? p.ldr : p.ldaux;
     bf16x8 pre[8];
     for (int q = 0; q < S + 2; ++q) {
+      const unsigned long long ts0 = PROF_T();
       __builtin_amdgcn_s_barrier();
+      PROF_ADD(7, PROF_T() - ts0);
       const int t = done_items;
       if (t >= nitems) continue;
       const int qd = (t + 1) * nk;
@@ -630,6 +645,9 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
       }
       if (sl + 1 == avail) { ++done_items; cur = locate(cur.idx + G); }
     }
+#ifdef DCC_RING_PROFILE
+    if (lane == 0 && wave == 8) atomicAdd(&g_prof[7], prof_acc[7]);
+#endif
   }
 }
 
