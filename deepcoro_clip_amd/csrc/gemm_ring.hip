@@ -641,6 +641,9 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+#ifdef DCC_RING_PROFILE
+        if (p.flags & 0x2000) continue;  // experiment: the epilogue crew computes but does not store
+#endif
         *reinterpret_cast<bf16x8*>(C + (int64_t)row * p.ldc + col) = o;
       }
       if (sl + 1 == avail) { ++done_items; cur = locate(cur.idx + G); }

@@ -18,4 +18,7 @@ def run(M, N, Kd, **kw):
     v = [x / reps / 256 for x in buf]
     us = s.elapsed_time(e) / reps * 1e3
     print(f"M{M} N{N} K{Kd}: {us:.1f} us; per workgroup (memtime ticks, 100 MHz): steps {v[3]:.0f} | consumer: barrier-wait {v[0]:.0f} mfma {v[1]:.0f} dump {v[2]:.0f} | loader: vmwait {v[4]:.0f} barrier {v[5]:.0f} issue {v[6]:.0f} | storer barrier-wait {v[7]:.0f}")
-run(37656, 1536, 384); run(37656, 384, 1536); run(37656, 384, 384); run(8192, 8192, 8192)
+for v in (0, 7, 4):
+    K.GEMM_VARIANT = v << 8
+    print("variant", v, "(7 = storers do not store, 4 = loaders do not load)")
+    run(37656, 1536, 384); run(37656, 1152, 384); run(37656, 384, 1536)
