@@ -78,6 +78,7 @@ def build_job(args, device, world, rank):
     videos = torch.randn(shape, generator=g).to(device)
     ids = torch.randint(0, 30522, (args.batch, args.seq), generator=g).to(device)
     mask = torch.ones(args.batch, args.seq, dtype=torch.int64, device=device)
+    runner._use_step_graph = bool(getattr(args, "graph", False)) and world == 1
     return runner, dict(videos=videos, input_ids=ids, attention_mask=mask)
 
 
@@ -157,6 +158,7 @@ def main():
     ap.add_argument("--seq", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--pooling", default="mean", choices=["mean", "attention"])
+    ap.add_argument("--graph", action="store_true", help="replay forward+backward+clip from a HIP graph (1 rank; pays when the step is host-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-kernels", type=int, default=0, help="print the N slowest timed kernel shapes (stderr)")

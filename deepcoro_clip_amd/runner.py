@@ -118,6 +118,9 @@ class VideoContrastiveLearningRunner:
         self._orphan_clipper: GradClipper | None = None
         self._text_stream: torch.cuda.Stream | None = None
         self._accum_grad: torch.Tensor | None = None
+        self._use_step_graph = bool(_cfg(config, "use_step_graph", False)) or os.environ.get("DCC_STEP_GRAPH", "0") == "1"
+        self._graphs: dict = {}
+        self._graph_stream: torch.cuda.Stream | None = None
 
     # ------------------------------------------------------------------------------------------ helpers
     def _scheduler_is_per_iteration(self) -> bool:
@@ -293,6 +296,15 @@ class VideoContrastiveLearningRunner:
                     text_metadata: Optional[List[Dict[str, Any]]] = None,
                     debug_sample_info: Optional[List[Dict[str, Any]]] = None) -> tuple[dict, dict]:
         accum = int(_cfg(self.config, "gradient_accumulation_steps", 1))
+        if self._graph_eligible(accum, positive_mask, text_metadata):
+            return self._graph_train_step(videos, input_ids, attention_mask)
+        total_loss, video_emb, text_emb, diag = self._forward_backward(videos, input_ids, attention_mask, positive_mask,
+                                                                       positive_weights, text_metadata, accum)
+        boundary = (self.step + 1) % accum == 0
+        fused_clip = self._reduce_and_clip() if boundary else None
+        return self._finish_step(boundary, fused_clip, total_loss, video_emb, text_emb, diag)
+
+    def _forward_backward(self, videos, input_ids, attention_mask, positive_mask, positive_weights, text_metadata, accum):
         if self.step % accum == 0:
             self._zero_grad()
         video_emb, text_emb = self._encode(videos, input_ids, attention_mask)
@@ -303,35 +315,40 @@ class VideoContrastiveLearningRunner:
             self._accum_grad_val = 1.0 / accum
             self._accum_grad = torch.full((), 1.0 / accum, device=clip_loss.device, dtype=clip_loss.dtype)
         total_loss.backward(self._accum_grad)  # == (loss / accum).backward() without an extra kernel
+        return total_loss, video_emb, text_emb, diag
 
-        boundary = (self.step + 1) % accum == 0
+    def _reduce_and_clip(self):
+        """Join the gradient all-reduces, compute the clip coefficient; returns it when the optimizer applies it on the fly."""
         max_norm = _cfg(self.config, "max_grad_norm", 5.0)
+        for w in self._ddp_wrappers():
+            w.finish()  # join the overlapped bucket all-reduces (RCCL)
+        fused_clip = None
+        if max_norm:
+            if self._clipper is None:
+                self._clipper = GradClipper(self._all_encoder_params())
+                self._clipped_ids = {id(p) for p in self._clipper.params}
+                # clipped parameters outside every optimizer group (the reference's video `proj`, SURVEY §9.11):
+                # nobody zeroes their .grad, so it keeps accumulating and keeps being rescaled in place — that
+                # history feeds the norm of every later step and must be reproduced
+                in_opt = {id(p) for g in self.optimizer.param_groups for p in g["params"]}
+                orphans = [p for p in self._clipper.params if id(p) not in in_opt]
+                self._orphan_clipper = GradClipper(orphans) if orphans else None
+            fuse = isinstance(self.optimizer, HipAdamW)  # the update kernel applies the coefficient on the fly
+            self._clipper.clip_(float(max_norm), scale=not fuse)
+            fused_clip = self._clipper.coef if fuse else None
+            if fuse and self._orphan_clipper is not None:
+                self._orphan_clipper.scale_with(self._clipper.coef)
+        if isinstance(self.log_temp, torch.nn.Parameter) and self.log_temp.grad is not None and dist.is_available() \
+                and dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(self.log_temp.grad, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(self.log_temp.grad, op=dist.ReduceOp.SUM)
+                self.log_temp.grad.div_(dist.get_world_size())
+        return fused_clip
+
+    def _finish_step(self, boundary: bool, fused_clip, total_loss, video_emb, text_emb, diag, static_outputs: bool = False):
         if boundary:
-            for w in self._ddp_wrappers():
-                w.finish()  # join the overlapped bucket all-reduces (RCCL)
-            fused_clip = None
-            if max_norm:
-                if self._clipper is None:
-                    self._clipper = GradClipper(self._all_encoder_params())
-                    self._clipped_ids = {id(p) for p in self._clipper.params}
-                    # clipped parameters outside every optimizer group (the reference's video `proj`):
-                    # nobody zeroes their .grad, so it keeps accumulating and keeps being rescaled in place — that
-                    # history feeds the norm of every later step and must be reproduced
-                    in_opt = {id(p) for g in self.optimizer.param_groups for p in g["params"]}
-                    orphans = [p for p in self._clipper.params if id(p) not in in_opt]
-                    self._orphan_clipper = GradClipper(orphans) if orphans else None
-                fuse = isinstance(self.optimizer, HipAdamW)  # the update kernel applies the coefficient on the fly
-                self._clipper.clip_(float(max_norm), scale=not fuse)
-                fused_clip = self._clipper.coef if fuse else None
-                if fuse and self._orphan_clipper is not None:
-                    self._orphan_clipper.scale_with(self._clipper.coef)
-            if isinstance(self.log_temp, torch.nn.Parameter) and self.log_temp.grad is not None and dist.is_available() \
-                    and dist.is_initialized() and dist.get_world_size() > 1:
-                if dist.get_backend() == "nccl":
-                    dist.all_reduce(self.log_temp.grad, op=dist.ReduceOp.AVG)
-                else:
-                    dist.all_reduce(self.log_temp.grad, op=dist.ReduceOp.SUM)
-                    self.log_temp.grad.div_(dist.get_world_size())
             if fused_clip is not None:
                 self.optimizer.step(grad_scale=fused_clip, scaled=self._clipped_ids)
             else:
@@ -341,12 +358,75 @@ class VideoContrastiveLearningRunner:
             if self.lr_scheduler and self.scheduler_per_iteration and self.step > 0:
                 self.lr_scheduler.step()
         self.step += 1
-
         with torch.no_grad():
             batch_metrics = self._step_metrics(total_loss, video_emb, text_emb, diag)
             video_fp32 = video_emb.detach().float()
             text_fp32 = text_emb.detach().float() if text_emb is not None else torch.empty(0, device=video_fp32.device)
+            if static_outputs:  # replayed graphs rewrite their output buffers: hand out copies
+                if video_fp32.data_ptr() == video_emb.data_ptr():
+                    video_fp32 = video_fp32.clone()
+                if text_emb is not None and text_fp32.data_ptr() == text_emb.data_ptr():
+                    text_fp32 = text_fp32.clone()
         return batch_metrics, {"video_embeddings": video_fp32, "text_embeddings": text_fp32}
+
+    # ------------------------------------------------------------------------------------ HIP-graph step (opt-in)
+    def _graph_eligible(self, accum: int, positive_mask, text_metadata) -> bool:
+        """The step can be replayed from a HIP graph when nothing in it depends on per-step host state: one rank,
+        no accumulation, the HIP AdamW (its table upload and launch stay outside the graph), the plain pair loss."""
+        if not self._use_step_graph:
+            return False
+        return (self.world_size == 1 and not self._ddp_wrappers() and accum == 1 and isinstance(self.optimizer, HipAdamW)
+                and positive_mask is None and not text_metadata and self.video_encoder.training and torch.is_grad_enabled())
+
+    def _graph_train_step(self, videos, input_ids, attention_mask):
+        """forward + loss + backward + clip replayed from a captured graph (one launch instead of ~1400); the optimizer
+        launch, the scheduler and the metric copy follow eagerly.  The first calls with a new input signature run eagerly
+        on the capture stream (warm-up: allocator, lazy state, autograd's accumulate nodes), then the step is captured;
+        a step that draws host-seeded randomness (dropout) is never captured."""
+        import gc
+
+        key = (tuple(videos.shape), videos.dtype, None if input_ids is None else tuple(input_ids.shape))
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._graphs[key] = {"calls": 0, "graph": None, "eager_only": False}
+        if self._graph_stream is None:
+            self._graph_stream = torch.cuda.Stream(device=videos.device)
+        side, cur = self._graph_stream, torch.cuda.current_stream()
+        if st["graph"] is None:
+            if st["eager_only"] or st["calls"] < 3:
+                st["calls"] += 1
+                drops = Fn._DROPOUT_CALLS
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    out = self._forward_backward(videos, input_ids, attention_mask, None, None, None, 1)
+                    clip = self._reduce_and_clip()
+                    res = self._finish_step(True, clip, *out)
+                cur.wait_stream(side)
+                for t in (videos, input_ids, attention_mask):
+                    if t is not None:
+                        t.record_stream(side)
+                if Fn._DROPOUT_CALLS != drops:
+                    st["eager_only"] = True   # host-seeded dropout masks would be frozen into the graph
+                return res
+            st["inputs"] = [None if t is None else t.clone() for t in (videos, input_ids, attention_mask)]
+            gc.collect()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                st["out"] = self._forward_backward(*st["inputs"], None, None, None, 1)
+                st["clip"] = self._reduce_and_clip()
+            st["graph"] = g
+            st["grads"] = [(p, p.grad) for grp in self.optimizer.param_groups for p in grp["params"]] + \
+                          [(p, p.grad) for p in (self._clipper.params if self._clipper is not None else [])]
+        else:
+            for dst, src in zip(st["inputs"], (videos, input_ids, attention_mask)):
+                if dst is not None:
+                    dst.copy_(src, non_blocking=True)
+        st["graph"].replay()
+        for p, gr in st["grads"]:   # the replay rewrote these buffers; keep .grad pointing at them (eager steps of another
+            if p.grad is not gr:    # signature may have re-homed the gradients in between)
+                p.grad = gr
+        return self._finish_step(True, st["clip"], *st["out"], static_outputs=True)
 
     def _val_step(self, videos: torch.Tensor, input_ids: Optional[torch.Tensor] = None,
                   attention_mask: Optional[torch.Tensor] = None, positive_mask: Optional[torch.Tensor] = None,

@@ -228,3 +228,31 @@ def test_step_metrics_resolve_lazily_with_reference_keys():
     assert plain == m and {**m} == plain and json.loads(json.dumps(m)) == plain and m.copy() == plain
     assert m.get("nope", 7) == 7 and "loss" in m and len(m) == len(plain)
     assert emb["video_embeddings"].shape == (2, 512) and emb["text_embeddings"].shape == (2, 512)
+
+
+def test_hip_graph_step_matches_eager_steps():
+    """Opt-in HIP-graph replay of forward + loss + backward + clip (runner._graph_train_step): same losses and parameters
+    as the eager step on changing batches; warm-up calls run eagerly, the 4th call captures."""
+    import __graft_entry__ as ge
+
+    def run(use_graph):
+        runner, _, (videos, ids, mask) = ge.make_tiny_setup(torch.float32, seed=3)
+        runner._use_step_graph = use_graph
+        g = torch.Generator().manual_seed(11)
+        losses = []
+        for i in range(8):
+            v = (videos + 0.05 * torch.randn(videos.shape, generator=g)).cuda()
+            idb = torch.randint(0, 512, ids.shape, generator=g).cuda()
+            m, emb = runner._train_step(videos=v, input_ids=idb, attention_mask=mask.cuda())
+            losses.append(m["loss"])
+            assert emb["video_embeddings"].shape == (2, 512)
+        torch.cuda.synchronize()
+        return runner, losses
+
+    eager, le = run(False)
+    graph, lg = run(True)
+    assert any(st["graph"] is not None for st in graph._graphs.values()), "the step was never captured"
+    assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-5 * max(1.0, max(abs(x) for x in le)), (le, lg)
+    for (n, p), (_, q) in zip(eager.text_encoder.named_parameters(), graph.text_encoder.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), n
+    assert eager.step == graph.step == 8
