@@ -998,6 +998,118 @@ __global__ __launch_bounds__(256) void dw3_wgrad_kernel(const TD* __restrict__ d
   }
 }
 
+// Weight gradient, marching variant: thread = (chunk, row tap kh, run slot) walks the output frames to = 0..To-1 of one
+// (clip, head, output row, column run).  The input row of frame t is loaded ONCE and serves the temporal taps kt = 0, 1, 2
+// of the outputs to = t+1, t, t-1 from a rolling three-row window in registers, and the dy run is loaded once per frame:
+// 16 loads per (output run, frame, kh) instead of 34 per (output run, kt).  The next frame's row / dy run are requested
+// before the current frame's FMAs.  Partials: same block fold as dw3_wgrad_kernel (tap = (kt*3 + kh)*3 + kw).
+template <typename T, typename TD, int S, int WT>
+__global__ __launch_bounds__(256) void dw3_wgrad_march_kernel(const TD* __restrict__ dy, const T* __restrict__ x,
+                                                              float* __restrict__ ws, RunGeom r, int iters, int nruns) {
+  constexpr int CV = Vec16<T>::N;
+  constexpr int SEG = (WT - 1) * S + 3;
+  constexpr int PITCH = 9 * CV + 1;
+  extern __shared__ __attribute__((aligned(16))) float red3[];  // [256][PITCH]
+  const PoolGeom& g = r.g;
+  const unsigned slot = fdiv(threadIdx.x, r.d_cpr);
+  const int c = threadIdx.x - slot * r.cpr;
+  const int slots3 = r.slots / 3;
+  const int kh = slot % 3, rsl = slot / 3;
+  float acc[9][CV];  // [kt*3 + kw]
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int e = 0; e < CV; ++e) acc[k][e] = 0.0f;
+  const __amdgpu_buffer_rsrc_t rsx = span_rsrc(x, r.xspan), rsy = span_rsrc(dy, r.yspan);
+  if ((int)slot < slots3 * 3) {
+    for (int it = 0; it < iters; ++it) {
+      const unsigned run = (blockIdx.x * iters + it) * slots3 + rsl;
+      if ((int)run >= nruns) break;
+      // run -> (b, head, ho, first output column)
+      const unsigned t1 = fdiv(run, r.d_runsW);
+      const int w0 = (run - t1 * r.runsW) * WT;
+      const unsigned t2 = fdiv(t1, r.d_Ho);
+      const int ho = t1 - t2 * g.Ho;
+      const unsigned b = fdiv(t2, r.d_H);
+      const int hd = t2 - b * g.H;
+      const int hh = ho * S + kh - 1;
+      const bool rowok = hh >= 0 && hh < g.Hs;
+      const unsigned xbase = b * r.bxb + hd * r.bxh + c * (CV * (unsigned)sizeof(T));
+      const unsigned ybase = b * r.byb + hd * r.byh + c * (CV * (unsigned)sizeof(TD)) + (unsigned)(g.has_cls + ho * g.Wo + w0) * r.byn;
+      const int col0 = w0 * S - 1;
+      unsigned coff[SEG], doff[WT];
+#pragma unroll
+      for (int j = 0; j < SEG; ++j) {
+        const int col = col0 + j;
+        coff[j] = (col >= 0 && col < g.Ws) ? (unsigned)col * r.bxn : OOB;
+      }
+#pragma unroll
+      for (int i = 0; i < WT; ++i) doff[i] = (w0 + i < g.Wo) ? i * r.byn : OOB;
+      auto load_row = [&](RawCV<T, CV> (&dst)[SEG], int t) {
+        const unsigned row = (rowok && t >= 0 && t < g.T) ? xbase + (unsigned)(g.has_cls + (t * g.Hs + hh) * g.Ws) * r.bxn : OOB;
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) {
+          if (S > 2 && (j % S) > 2) continue;
+          dst[j] = load_raw_buf<T, CV>(rsx, sat_add(row, coff[j]));
+        }
+      };
+      auto load_dy = [&](RawCV<TD, CV> (&dst)[WT], int to) {
+        const unsigned row = (to < g.To) ? ybase + (unsigned)(to * g.Ho * g.Wo) * r.byn : OOB;
+#pragma unroll
+        for (int i = 0; i < WT; ++i) dst[i] = load_raw_buf<TD, CV>(rsy, sat_add(row, doff[i]));
+      };
+      RawCV<T, CV> rows[3][SEG];
+      RawCV<TD, CV> dcur[WT], dnext[WT];
+      load_row(rows[0], -1);  // zeros
+      load_row(rows[1], 0);
+      load_dy(dcur, 0);
+#pragma unroll 1
+      for (int to = 0; to < g.To; ++to) {
+        load_row(rows[2], to + 1);
+        load_dy(dnext, to + 1);
+        float dv[WT][CV];
+#pragma unroll
+        for (int i = 0; i < WT; ++i) raw_to_f32<TD, CV>(dcur[i], dv[i]);
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+          for (int j = 0; j < SEG; ++j) {
+            if (S > 2 && (j % S) > 2) continue;
+            float f[CV];
+            raw_to_f32<T, CV>(rows[kt][j], f);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              if ((j - kw) >= 0 && (j - kw) % S == 0 && (j - kw) / S < WT) {
+#pragma unroll
+                for (int e = 0; e < CV; ++e) acc[kt * 3 + kw][e] += dv[(j - kw) / S][e] * f[e];
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) { rows[0][j] = rows[1][j]; rows[1][j] = rows[2][j]; }
+#pragma unroll
+        for (int i = 0; i < WT; ++i) dcur[i] = dnext[i];
+      }
+    }
+  }
+  float* mine = red3 + threadIdx.x * PITCH;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int e = 0; e < CV; ++e) mine[k * CV + e] = acc[k][e];
+  __syncthreads();
+  float* part = ws + (int64_t)blockIdx.x * 27 * g.C;
+  for (int o = threadIdx.x; o < 27 * g.C; o += 256) {
+    const int tap = o / g.C, ch = o - tap * g.C;
+    const int okt = tap / 9, okh = (tap - okt * 9) / 3, okw = tap % 3;
+    const int oc = ch / CV, oe = ch - oc * CV;
+    float sum = 0.0f;
+    for (int s3 = 0; s3 < slots3; ++s3) sum += red3[((s3 * 3 + okh) * r.cpr + oc) * PITCH + (okt * 3 + okw) * CV + oe];
+    part[o] = sum;
+  }
+}
+
 RunGeom make_run_geom(const PoolGeom& g, int vec, int WT) {
   RunGeom r;
   r.g = g;
@@ -1264,28 +1376,40 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
     const int vec = dtype == DCC_BF16 ? 8 : 4;
     const int S = dw3_stride(g, vec);
     if (S && (256 / (g.C / vec)) >= 3) {
+      // marching kernel (default): runs of WM = 2 / 4 output columns keep the three-row window + 72 accumulators at
+      // 2-3 waves per SIMD; DCC_WGRAD_NO_MARCH=1 selects the per-temporal-tap kernel with runs of 7 / 4
+      static const bool march = !getenv("DCC_WGRAD_NO_MARCH");
+      static const int wm_env = getenv("DCC_WGRAD_WM") ? atoi(getenv("DCC_WGRAD_WM")) : 0;
+      const int WM = wm_env == 2 || wm_env == 4 ? wm_env : ((g.Wo % 4 == 0 && S == 1) ? 4 : 2);
       const bool w7 = (g.Wo % 7 == 0);
-      RunGeom r = make_run_geom(g, vec, w7 ? 7 : 4);
+      RunGeom r = make_run_geom(g, vec, march ? WM : (w7 ? 7 : 4));
       const bool spans_ok = set_spans(r, dtype == DCC_BF16 ? 2 : 4, grad_dtype == DCC_BF16 ? 2 : 4);
       const int slots3 = r.slots / 3;
-      const int total_iters = (r.runs + slots3 - 1) / slots3;
+      const int nruns = march ? g.B * g.H * g.Ho * r.runsW : r.runs;  // marching threads walk the frames themselves
+      const int total_iters = (nruns + slots3 - 1) / slots3;
       int nblocks = total_iters < 512 ? total_iters : 512;  // <= DCC_DWCONV_WS_BLOCKS; two 75-KB blocks per CU
       if (nblocks < 1) nblocks = 1;
       const int iters = (total_iters + nblocks - 1) / nblocks;
       nblocks = (total_iters + iters - 1) / iters;
       const size_t lds3 = (size_t)256 * (9 * vec + 1) * 4;
-#define DW3W(T_, TD_, S_, W_)                                                                                       \
+#define DW3K(KERN_, ...)                                                                                            \
   do {                                                                                                              \
-    auto kern = dw3_wgrad_kernel<T_, TD_, S_, W_>;                                                                  \
+    auto kern = KERN_;                                                                                              \
     static bool cfg = false;                                                                                        \
     if (!cfg) {                                                                                                     \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess) return DCC_ERR_LAUNCH; \
       cfg = true;                                                                                                   \
     }                                                                                                               \
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds3, s, (const TD_*)dy, (const T_*)x, workspace, r, iters); \
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds3, s, __VA_ARGS__);                                       \
   } while (0)
-#define DW3W_S(T_, TD_, W_) do { if (S == 1) DW3W(T_, TD_, 1, W_); else if (S == 2) DW3W(T_, TD_, 2, W_); else if (S == 4) DW3W(T_, TD_, 4, W_); else DW3W(T_, TD_, 8, W_); } while (0)
-#define DW3W_ALL(T_, TD_) do { if (w7) DW3W_S(T_, TD_, 7); else DW3W_S(T_, TD_, 4); } while (0)
+#define DW3W(T_, TD_, S_)                                                                                           \
+  do {                                                                                                              \
+    if (march && WM == 4) DW3K((dw3_wgrad_march_kernel<T_, TD_, S_, 4>), (const TD_*)dy, (const T_*)x, workspace, r, iters, nruns); \
+    else if (march) DW3K((dw3_wgrad_march_kernel<T_, TD_, S_, 2>), (const TD_*)dy, (const T_*)x, workspace, r, iters, nruns); \
+    else if (w7) DW3K((dw3_wgrad_kernel<T_, TD_, S_, 7>), (const TD_*)dy, (const T_*)x, workspace, r, iters);       \
+    else DW3K((dw3_wgrad_kernel<T_, TD_, S_, 4>), (const TD_*)dy, (const T_*)x, workspace, r, iters);               \
+  } while (0)
+#define DW3W_ALL(T_, TD_) do { if (S == 1) DW3W(T_, TD_, 1); else if (S == 2) DW3W(T_, TD_, 2); else if (S == 4) DW3W(T_, TD_, 4); else DW3W(T_, TD_, 8); } while (0)
       bool done = true;
       if (!spans_ok) done = false;
       else if (dtype == DCC_BF16 && grad_dtype == DCC_BF16) DW3W_ALL(bf16_t, bf16_t);
@@ -1293,8 +1417,8 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
       else if (dtype == DCC_F32 && grad_dtype == DCC_F32) DW3W_ALL(float, float);
       else done = false;
 #undef DW3W_ALL
-#undef DW3W_S
 #undef DW3W
+#undef DW3K
       if (done) {
         rc = dcc_check_launch();
         if (rc) return rc;
