@@ -124,16 +124,51 @@ def zeros_f32(shape, device) -> torch.Tensor:
     return ARENA.zeros(tuple(shape) if not isinstance(shape, int) else (shape,), device)
 
 
-def wgrad(g2: torch.Tensor, x2: torch.Tensor, colsum: torch.Tensor | None = None) -> torch.Tensor:
+# Weight gradients feed nothing until the optimizer, so they can leave the backward's critical chain: with WGRAD_SIDE
+# (set by the runner: one rank, no accumulation) a weight-gradient GEMM whose parameter has no gradient yet (AccumulateGrad
+# will adopt the buffer without touching it) runs on a side stream, filling the launch gaps and partial last waves of the
+# data-gradient chain; the main stream re-joins it in an end-of-backward engine callback.
+WGRAD_SIDE = False
+_WG = {"stream": None, "queued": False}
+
+
+def _join_wgrad():
+    _WG["queued"] = False
+    if _WG["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_WG["stream"])
+
+
+def grads_unset(*params) -> bool:
+    """True when none of the given tensors carries a .grad yet (then autograd adopts a fresh gradient buffer as is)."""
+    return all(p is None or getattr(p, "grad", None) is None for p in params)
+
+
+def wgrad(g2: torch.Tensor, x2: torch.Tensor, colsum: torch.Tensor | None = None, side: bool = False) -> torch.Tensor:
     """dW[n][k] = sum_rows g2[row][n] * x2[row][k] in fp32 (k-major GEMM; split over the row range when the
     n x k output alone cannot fill the chip, accumulating into a pre-zeroed arena slice)."""
     rows, N = g2.shape
     Kd = x2.shape[1]
     sk = K.wgrad_splitk(rows, N, Kd)
-    if sk > 1:
-        return K.gemm(g2, x2, a_km=True, b_km=True, out=zeros_f32((N, Kd), g2.device), accumulate=True, splitk=sk,
-                      colsum=colsum)
-    return K.gemm(g2, x2, a_km=True, b_km=True, out_dtype=torch.float32, colsum=colsum)
+    out = zeros_f32((N, Kd), g2.device) if sk > 1 else torch.empty((N, Kd), device=g2.device, dtype=torch.float32)
+    side = side and WGRAD_SIDE
+    if side and not _WG["queued"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_wgrad)
+            _WG["queued"] = True
+        except RuntimeError:  # not inside a backward pass: nobody would join the stream
+            side = False
+    if not side:
+        return K.gemm(g2, x2, a_km=True, b_km=True, out=out, accumulate=sk > 1, splitk=sk, colsum=colsum)
+    main = torch.cuda.current_stream()
+    if _WG["stream"] is None or _WG["stream"].device != g2.device:
+        _WG["stream"] = torch.cuda.Stream(device=g2.device)
+    ws = _WG["stream"]
+    ws.wait_stream(main)
+    with torch.cuda.stream(ws):
+        K.gemm(g2, x2, a_km=True, b_km=True, out=out, accumulate=sk > 1, splitk=sk, colsum=colsum)
+    g2.record_stream(ws)
+    x2.record_stream(ws)
+    return out
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -158,6 +193,7 @@ class LinearFn(torch.autograd.Function):
         pre = torch.empty((x2.shape[0], N), device=x.device, dtype=x.dtype) if gelu else None
         y = K.gemm(x2, wc, bias=bias.detach() if bias is not None else None, gelu=gelu, save_pre=gelu, aux=pre, resid=res2)
         ctx.save_for_backward(x2, wc, pre)
+        ctx.params = (weight, bias)
         ctx.gelu = gelu
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -177,7 +213,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if want_db:  # bias gradient rides in the weight-gradient GEMM (column sums of its k-major A operand)
                 db = zeros_f32(N, g.device)
-            dw = wgrad(g, x2, db)
+            dw = wgrad(g, x2, db, side=grads_unset(*ctx.params))
         elif want_db:
             db = K.colsum(g)
         if ctx.has_res and ctx.needs_input_grad[4]:
@@ -203,6 +239,7 @@ class MlpFn(torch.autograd.Function):
         res2 = _c(residual).reshape(-1, N) if residual is not None else None
         y = K.gemm(act, w2c, bias=b2.detach(), resid=res2)
         ctx.save_for_backward(x2, w1c, w2c, pre, act)
+        ctx.params = (w1, b1, w2, b2)
         ctx.has_res = residual is not None
         ctx.xshape = x.shape
         return y.reshape(*x.shape[:-1], N)
@@ -217,13 +254,13 @@ class MlpFn(torch.autograd.Function):
         f32 = dict(device=dy2.device, dtype=torch.float32)
         if ctx.needs_input_grad[3]:
             db2 = zeros_f32(N, dy2.device) if ctx.needs_input_grad[4] else None
-            dw2 = wgrad(dy2, act, db2)
+            dw2 = wgrad(dy2, act, db2, side=grads_unset(*ctx.params[2:]))
         elif ctx.needs_input_grad[4]:
             db2 = K.colsum(dy2)
         dpre = K.gemm(dy2, w2c, b_km=True, dgelu=True, aux=pre)
         if ctx.needs_input_grad[1]:
             db1 = zeros_f32(Hd, dy2.device) if ctx.needs_input_grad[2] else None
-            dw1 = wgrad(dpre, x2, db1)
+            dw1 = wgrad(dpre, x2, db1, side=grads_unset(*ctx.params[:2]))
         elif ctx.needs_input_grad[2]:
             db1 = K.colsum(dpre)
         if ctx.needs_input_grad[0]:

@@ -120,6 +120,7 @@ class VideoContrastiveLearningRunner:
         self._accum_grad: torch.Tensor | None = None
         self._use_step_graph = bool(_cfg(config, "use_step_graph", False)) or os.environ.get("DCC_STEP_GRAPH", "0") == "1"
         self._graphs: dict = {}
+        self._wgrad_side = os.environ.get("DCC_WGRAD_STREAM", "0") == "1"  # measured: +5 ms of host launch time > what it hides
         self._graph_stream: torch.cuda.Stream | None = None
 
     # ------------------------------------------------------------------------------------------ helpers
@@ -314,7 +315,12 @@ class VideoContrastiveLearningRunner:
         if self._accum_grad is None or float(self._accum_grad_val) != 1.0 / accum:
             self._accum_grad_val = 1.0 / accum
             self._accum_grad = torch.full((), 1.0 / accum, device=clip_loss.device, dtype=clip_loss.dtype)
-        total_loss.backward(self._accum_grad)  # == (loss / accum).backward() without an extra kernel
+        # weight-gradient GEMMs off the critical chain (functional.wgrad): safe when every gradient buffer is adopted as is
+        Fn.WGRAD_SIDE = self._wgrad_side and accum == 1 and self.world_size == 1 and not self._ddp_wrappers()
+        try:
+            total_loss.backward(self._accum_grad)  # == (loss / accum).backward() without an extra kernel
+        finally:
+            Fn.WGRAD_SIDE = False
         return total_loss, video_emb, text_emb, diag
 
     def _reduce_and_clip(self):
