@@ -351,6 +351,9 @@ int ln_bwd_t(const void* dy, int64_t lddy, const void* x, int64_t ldx, const flo
   const unsigned ws_fit = (1u << 20) / (unsigned)(2 * C);  // block partials the workspace holds (DCC_LN_WS_FLOATS in include/dcc.h)
   const unsigned ws_cap = ws_fit < lnb_cap_ws ? ws_fit : lnb_cap_ws;
   unsigned nb = 0;
+  // few rows (the text tower's 768-token norms, the aggregator): a grid of <= 128 blocks pays ~2 us for the atomic tail,
+  // less than the fold kernel's launch
+  if (ws && rows <= 128 * 8) ws = nullptr;
   static const int lnb_u = getenv("DCC_LNB_U") ? atoi(getenv("DCC_LNB_U")) : 2;
 #define LN_BU(LP, IT, UU) hipLaunchKernelGGL((ln_bwd_kernel<T, TD, LP, IT, UU>), dim3(nb = lnb_grid(rows, 64 / LP * UU, ws ? ws_cap : lnb_cap)), dim3(256), 2 * C * sizeof(float), st, dyp, lddy, xp, ldx, mean, rstd, g, dxp, lddx, dgamma, dbeta, rows, C, drp, ws)
 #define LN_B(LP, IT) do { if (lnb_u == 4 && IT == 1) LN_BU(LP, IT, 4); else if (lnb_u >= 2 && IT <= 2) LN_BU(LP, IT, 2); else LN_BU(LP, IT, 1); } while (0)
