@@ -17,6 +17,7 @@ from __future__ import annotations
 import itertools
 import math
 import os
+import time
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -118,7 +119,9 @@ class VideoContrastiveLearningRunner:
         self._orphan_clipper: GradClipper | None = None
         self._text_stream: torch.cuda.Stream | None = None
         self._accum_grad: torch.Tensor | None = None
-        self._use_step_graph = bool(_cfg(config, "use_step_graph", False)) or os.environ.get("DCC_STEP_GRAPH", "0") == "1"
+        self._use_step_graph = _cfg(config, "use_step_graph", False)  # False | True | "auto"
+        if os.environ.get("DCC_STEP_GRAPH") in ("1", "auto"):
+            self._use_step_graph = True if os.environ["DCC_STEP_GRAPH"] == "1" else "auto"
         self._graphs: dict = {}
         self._wgrad_side = os.environ.get("DCC_WGRAD_STREAM", "0") == "1"  # measured: +5 ms of host launch time > what it hides
         self._graph_stream: torch.cuda.Stream | None = None
@@ -399,14 +402,32 @@ class VideoContrastiveLearningRunner:
             self._graph_stream = torch.cuda.Stream(device=videos.device)
         side, cur = self._graph_stream, torch.cuda.current_stream()
         if st["graph"] is None:
+            if st["calls"] == 3 and not st["eager_only"] and self._use_step_graph == "auto":
+                # "auto": replay only when launching the step costs the host about as long as the GPU needs to run it
+                # (slow host cores, small inputs); a clearly GPU-bound step stays eager (hipGraphLaunch itself is ~1 ms
+                # slower per step there).  Measured on the warm-up calls: host time of the call vs event time on the GPU.
+                torch.cuda.synchronize()
+                host = st["host_ms"][-1]                       # the last warm-up call is the closest to steady state
+                gpu = st["events"][-1][0].elapsed_time(st["events"][-1][1])
+                st["eager_only"] = host < 0.95 * gpu           # GPU-bound: ~0.90 on a fast host; host-bound: ~1.0
+                st["decision"] = (host, gpu)
             if st["eager_only"] or st["calls"] < 3:
+                if st["eager_only"] and st["calls"] >= 3:  # settled on eager: the ordinary path on the caller's stream
+                    out = self._forward_backward(videos, input_ids, attention_mask, None, None, None, 1)
+                    return self._finish_step(True, self._reduce_and_clip(), *out)
                 st["calls"] += 1
                 drops = Fn._DROPOUT_CALLS
                 side.wait_stream(cur)
+                t0 = time.perf_counter()
                 with torch.cuda.stream(side):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                     out = self._forward_backward(videos, input_ids, attention_mask, None, None, None, 1)
                     clip = self._reduce_and_clip()
                     res = self._finish_step(True, clip, *out)
+                    e1.record()
+                st.setdefault("host_ms", []).append(1e3 * (time.perf_counter() - t0))
+                st.setdefault("events", []).append((e0, e1))
                 cur.wait_stream(side)
                 for t in (videos, input_ids, attention_mask):
                     if t is not None:
