@@ -79,8 +79,11 @@ class _NoCtx:
 _NOCTX = _NoCtx()
 
 
-def _timed(family: str, units: float, label: str = "", nbytes: float = 0.0):
-    return TIMER.time(family, units, label, nbytes) if TIMER is not None else _NOCTX
+def _timed(family: str, units: float, label=None, nbytes: float = 0.0):
+    """`label` may be a callable: the launch path must not pay for formatting a string nobody reads (~3 us x 500 GEMMs)."""
+    if TIMER is None:
+        return _NOCTX
+    return TIMER.time(family, units, label() if callable(label) else (label or ""), nbytes)
 
 
 def _i64(vals):
@@ -141,7 +144,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
     nbytes = (M * K + N * K) * a.element_size() + M * N * osz * (2 if accumulate else 1)
     nbytes += M * N * osz * (int(resid is not None) + int(save_pre)) + M * N * a.element_size() * int(dgelu)
     with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K,
-                f"M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk} f{flags} out{out.dtype}", nbytes):
+                lambda: f"M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk} f{flags} out{out.dtype}", nbytes):
         L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), L.ptr(resid), L.ptr(aux), L.ptr(colsum),
                a.stride(0), b.stride(0), out.stride(0), resid.stride(0) if resid is not None else 0,
                aux.stride(0) if aux is not None else 0, M, N, K, 1, 0, 0, 0, splitk, float(alpha), flags, int(a_km),
@@ -156,7 +159,7 @@ def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=N
     flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_ACCUM if accumulate else 0) | GEMM_VARIANT
     nbytes = batch * ((M * K + N * K) * a.element_size() + M * N * out.element_size() * (2 if accumulate else 1))
     with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * batch,
-                f"batched{batch} M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk}", nbytes):
+                lambda: f"batched{batch} M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk}", nbytes):
         L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), None, None, None, lda, ldb, ldc, 0, 0, M, N, K, batch,
                sA, sB, sC, splitk, float(alpha), flags, int(a_km), int(b_km), L.dt(a), L.dt(out), L.stream())
     return out
@@ -196,7 +199,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: float,
     if kbias is not None:
         assert kbias.shape == (B, Nk) and kbias.dtype == torch.float32 and kbias.is_contiguous()
     st = _i64(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o))
-    with _timed("attn_fwd", 2.0 * B * H * Nq * Nk * (DQK + DV), f"B{B} H{H} Nq{Nq} Nk{Nk} D{DQK}/{DV}"):
+    with _timed("attn_fwd", 2.0 * B * H * Nq * Nk * (DQK + DV), lambda: f"B{B} H{H} Nq{Nq} Nk{Nk} D{DQK}/{DV}"):
         L.call("dcc_attn_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(kbias),
                L.ptr(q) if residual else None, int(res_start), st, B, H, Nq, Nk, DQK, DV, float(scale), L.dt(q),
                L.stream())
@@ -224,7 +227,7 @@ def attn_bwd(q, k, v, o, do, lse, *, scale: float, kbias=None, residual: bool = 
     dvec = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
     st = _i64(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o) + _strides3(dq) + _strides3(dk) + _strides3(dv))
     # dQ kernel: S, dP, dQ products; dK/dV kernel: S, dP, dV, dK products
-    with _timed("attn_bwd", 2.0 * B * H * Nq * Nk * (3 * DQK + 4 * DV), f"B{B} H{H} Nq{Nq} Nk{Nk} D{DQK}/{DV} qs{qsplit}"):
+    with _timed("attn_bwd", 2.0 * B * H * Nq * Nk * (3 * DQK + 4 * DV), lambda: f"B{B} H{H} Nq{Nq} Nk{Nk} D{DQK}/{DV} qs{qsplit}"):
         L.call("dcc_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(dvec),
                L.ptr(kbias), L.ptr(q) if residual else None, int(res_start), L.ptr(dq), L.ptr(dk), L.ptr(dv), st, B, H,
                Nq, Nk, DQK, DV, float(scale), int(qsplit), L.dt(q), L.stream())
