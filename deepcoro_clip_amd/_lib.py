@@ -84,15 +84,14 @@ def dt(t_or_dtype) -> int:
 
 
 def ptr(t):
-    if t is None:
-        return None
-    return ctypes.c_void_p(t.data_ptr())
+    """Device address as a plain int (argtypes are c_void_p, ctypes converts; no c_void_p object per argument)."""
+    return None if t is None else t.data_ptr()
 
 
-def stream() -> ctypes.c_void_p:
+def stream() -> int:
     """Raw hipStream_t of torch's current stream (the C getters: `torch.cuda.current_stream()` builds a Stream object
     and resolves the device through several Python layers, ~9 us x several hundred launches per step on the host)."""
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def require_cuda(*tensors) -> None:

@@ -265,7 +265,7 @@ def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dgamma, dbeta, dx: torch.Tensor 
     assert dx.dtype == dy2d.dtype and dx.stride(1) == 1
     assert dres is None or (dres.shape == (rows, C) and dres.dtype == dx.dtype and dres.stride() == dx.stride())
     stream = L.stream()
-    key = (dy2d.device.index, stream.value)  # block partials of dgamma/dbeta; one per stream (the branches overlap)
+    key = (dy2d.device.index, stream)  # block partials of dgamma/dbeta; one per stream (the branches overlap)
     ws = _LN_WS.get(key)
     if ws is None:
         ws = _LN_WS[key] = torch.empty(1 << 20, device=dy2d.device, dtype=torch.float32)  # DCC_LN_WS_FLOATS
@@ -346,7 +346,7 @@ def dwconv_bwd_weight(dy: torch.Tensor, x: torch.Tensor, g: PoolGeom, dw: torch.
     L.require_cuda(dy, x, dw)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
     n = 1024 * g.C * g.kernel[0] * g.kernel[1] * g.kernel[2]  # DCC_DWCONV_WS_BLOCKS x taps x C
-    key = (dy.device.index, n, L.stream().value)  # one scratch buffer per stream: the
+    key = (dy.device.index, n, L.stream())  # one scratch buffer per stream: the
     ws = _DWCONV_WS.get(key)                                                      # q/k/v branches run concurrently
     if ws is None:
         ws = _DWCONV_WS[key] = torch.empty(n, device=dy.device, dtype=torch.float32)
