@@ -443,9 +443,17 @@ class VideoContrastiveLearningRunner:
             gc.collect()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                st["out"] = self._forward_backward(*st["inputs"], None, None, None, 1)
-                st["clip"] = self._reduce_and_clip()
+            step0 = self.step
+            try:
+                with torch.cuda.graph(g, stream=side):
+                    st["out"] = self._forward_backward(*st["inputs"], None, None, None, 1)
+                    st["clip"] = self._reduce_and_clip()
+            except Exception as e:  # a step that cannot be captured keeps running eagerly (nothing was executed yet)
+                print(f"[runner] HIP-graph capture of the step failed ({type(e).__name__}: {e}); staying eager")
+                torch.cuda.synchronize()
+                st["eager_only"], self.step = True, step0
+                out = self._forward_backward(videos, input_ids, attention_mask, None, None, None, 1)
+                return self._finish_step(True, self._reduce_and_clip(), *out)
             st["graph"] = g
             st["grads"] = [(p, p.grad) for grp in self.optimizer.param_groups for p in grp["params"]] + \
                           [(p, p.grad) for p in (self._clipper.params if self._clipper is not None else [])]
