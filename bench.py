@@ -228,6 +228,7 @@ def main():
     if not args.no_roofline:
         K.TIMER = K.KernelTimer()
         runner._use_step_graph = False  # the event pairs bracket individual launches: instrumented pass always eager
+        runner._wgrad_side = False      # ... and on the stream the timer records its events on
         for _ in range(args.steps):
             mi, _ = runner._train_step(**batch)
             mi["loss"]  # read like _run_epoch does: a per-step drain keeps the event pairs free of the launch-queue

@@ -159,13 +159,13 @@ def wgrad(g2: torch.Tensor, x2: torch.Tensor, colsum: torch.Tensor | None = None
             side = False
     if not side:
         return K.gemm(g2, x2, a_km=True, b_km=True, out=out, accumulate=sk > 1, splitk=sk, colsum=colsum)
-    main = torch.cuda.current_stream()
     if _WG["stream"] is None or _WG["stream"].device != g2.device:
         _WG["stream"] = torch.cuda.Stream(device=g2.device)
-    ws = _WG["stream"]
-    ws.wait_stream(main)
-    with torch.cuda.stream(ws):
-        K.gemm(g2, x2, a_km=True, b_km=True, out=out, accumulate=sk > 1, splitk=sk, colsum=colsum)
+        _WG["event"] = torch.cuda.Event()
+    ws, ev = _WG["stream"], _WG["event"]
+    ev.record()            # g2 / x2 are complete on the current stream here
+    ws.wait_event(ev)
+    K.gemm(g2, x2, a_km=True, b_km=True, out=out, accumulate=sk > 1, splitk=sk, colsum=colsum, stream=ws.cuda_stream)
     g2.record_stream(ws)
     x2.record_stream(ws)
     return out

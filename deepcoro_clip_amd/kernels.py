@@ -99,8 +99,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
          resid: torch.Tensor | None = None, aux: torch.Tensor | None = None, gelu: bool = False,
          save_pre: bool = False, dgelu: bool = False, out: torch.Tensor | None = None, accumulate: bool = False,
          out_dtype: torch.dtype | None = None, splitk: int = 1, alpha: float = 1.0,
-         colsum: torch.Tensor | None = None) -> torch.Tensor:
-    """C[m,n] = alpha * sum_k A(m,k) B(n,k) with fused epilogue.  `colsum` (fp32 [M], accumulated into; a_km only)
+         colsum: torch.Tensor | None = None, stream: int | None = None) -> torch.Tensor:
+    """C[m,n] = alpha * sum_k A(m,k) B(n,k) with fused epilogue.  `stream`: raw hipStream_t to launch on (default: torch's
+    current stream).  `colsum` (fp32 [M], accumulated into; a_km only)
     receives sum_k A(m,k) — the bias gradient of a Linear layer for free inside its weight-gradient GEMM.
 
     a: [M,K] (or [K,M] if a_km); b: [N,K] (or [K,N] if b_km); 2-D, inner stride 1.
@@ -148,7 +149,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
         L.call("dcc_gemm", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(bias), L.ptr(resid), L.ptr(aux), L.ptr(colsum),
                a.stride(0), b.stride(0), out.stride(0), resid.stride(0) if resid is not None else 0,
                aux.stride(0) if aux is not None else 0, M, N, K, 1, 0, 0, 0, splitk, float(alpha), flags, int(a_km),
-               int(b_km), L.dt(a), L.dt(out), L.stream())
+               int(b_km), L.dt(a), L.dt(out), L.stream() if stream is None else stream)
     return out
 
 
