@@ -684,7 +684,9 @@ class VideoContrastiveLearningRunner:
         raise NotImplementedError("Validation is not implemented for this runner")
 
     def inference(self, text_embeddings: torch.Tensor | None = None, topk: int = 5):
-        """Top-k text retrieval for every validation video (reference :1731-1758): [B,512] x [512,M] + top-k."""
+        """Top-k text retrieval for every validation video (reference :1731-1758): [B,512] x [512,M] raw inner products
+        (`torch.matmul(video_embeddings, text_embeddings.t())`, no normalisation) + top-k indices.  The reference then
+        averages metadata rows of a parquet file over those indices (pandas, out of scope); the bank is passed in."""
         if text_embeddings is None:
             raise ValueError("inference() needs the [M, 512] text embedding bank")
         self.video_encoder.eval()
@@ -693,7 +695,7 @@ class VideoContrastiveLearningRunner:
             bank = text_embeddings.to(self.device).float().contiguous()
             for batch in self.val_loader:
                 v = self.video_encoder(batch["videos"].to(self.device).float())
-                sim = compute_similarity_matrix(v, bank)
+                sim = K.gemm(v.float().contiguous(), bank)  # raw inner products, not cosines: reference :1757
                 results.append(K.topk_rows(sim.float().contiguous(), min(topk, bank.shape[0]))[1].cpu())
         return torch.cat(results, 0) if results else torch.empty(0, dtype=torch.long)
 

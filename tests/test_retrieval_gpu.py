@@ -160,3 +160,18 @@ def test_val_epoch_reencodes_unique_texts_and_ranks_index_sets(tmp_path):
     batches[0]["reports"] = ["", "severe stenosis of the lad"]
     with pytest.raises(ValueError):
         runner._run_epoch("val", 0)
+
+
+def test_inference_topk_uses_raw_inner_products_like_the_reference():
+    """inference(): torch.topk(video_embeddings @ text_embeddings.T, k) — unnormalised (reference runner :1757-1758)."""
+    import __graft_entry__ as ge
+
+    runner, _, (videos, ids, mask) = ge.make_tiny_setup(torch.float32, B=2)
+    g = torch.Generator().manual_seed(9)
+    bank = torch.randn(37, 512, generator=g) * torch.linspace(0.2, 3.0, 37)[:, None]  # very different text norms
+    runner.val_loader = [{"videos": torch.randn(2, *videos.shape[1:], generator=g)} for _ in range(2)]
+    got = runner.inference(text_embeddings=bank, topk=5)
+    runner.video_encoder.eval()
+    with torch.no_grad():
+        v = torch.cat([runner.video_encoder(b["videos"].cuda()).float().cpu() for b in runner.val_loader])
+    assert torch.equal(got, torch.topk(v @ bank.t(), 5, dim=1)[1])
