@@ -140,7 +140,7 @@ def _join_wgrad():
 
 def grads_unset(*params) -> bool:
     """True when none of the given tensors carries a .grad yet (then autograd adopts a fresh gradient buffer as is)."""
-    return all(p is None or getattr(p, "grad", None) is None for p in params)
+    return all(p is None or (p.is_leaf and p.grad is None) for p in params)  # non-leaf: not ours to reason about
 
 
 def wgrad(g2: torch.Tensor, x2: torch.Tensor, colsum: torch.Tensor | None = None, side: bool = False) -> torch.Tensor:
