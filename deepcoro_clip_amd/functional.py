@@ -213,7 +213,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if want_db:  # bias gradient rides in the weight-gradient GEMM (column sums of its k-major A operand)
                 db = zeros_f32(N, g.device)
-            dw = wgrad(g, x2, db, side=grads_unset(*ctx.params))
+            dw = wgrad(g, x2, db, side=WGRAD_SIDE and grads_unset(*ctx.params))
         elif want_db:
             db = K.colsum(g)
         if ctx.has_res and ctx.needs_input_grad[4]:
@@ -254,13 +254,13 @@ class MlpFn(torch.autograd.Function):
         f32 = dict(device=dy2.device, dtype=torch.float32)
         if ctx.needs_input_grad[3]:
             db2 = zeros_f32(N, dy2.device) if ctx.needs_input_grad[4] else None
-            dw2 = wgrad(dy2, act, db2, side=grads_unset(*ctx.params[2:]))
+            dw2 = wgrad(dy2, act, db2, side=WGRAD_SIDE and grads_unset(*ctx.params[2:]))
         elif ctx.needs_input_grad[4]:
             db2 = K.colsum(dy2)
         dpre = K.gemm(dy2, w2c, b_km=True, dgelu=True, aux=pre)
         if ctx.needs_input_grad[1]:
             db1 = zeros_f32(Hd, dy2.device) if ctx.needs_input_grad[2] else None
-            dw1 = wgrad(dpre, x2, db1, side=grads_unset(*ctx.params[:2]))
+            dw1 = wgrad(dpre, x2, db1, side=WGRAD_SIDE and grads_unset(*ctx.params[:2]))
         elif ctx.needs_input_grad[2]:
             db1 = K.colsum(dpre)
         if ctx.needs_input_grad[0]:
