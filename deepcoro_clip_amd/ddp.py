@@ -21,6 +21,8 @@ import torch.distributed as dist
 import torch.multiprocessing as MP
 import torch.utils.data.distributed as DS
 
+from . import _grad_slots
+
 
 class HipDDP(torch.nn.Module):
     def __init__(self, module: torch.nn.Module, device_ids=None, bucket_mb: float = 64.0, **_ignored):
@@ -68,24 +70,39 @@ class HipDDP(torch.nn.Module):
         self._order = ps
 
     def attach_grads(self):
-        """Zero the arena and (re)attach `param.grad` views; call instead of optimizer.zero_grad(set_to_none=True)."""
+        """Zero the arena and hand its slots out for this step; call instead of optimizer.zero_grad(set_to_none=True).
+
+        `param.grad` is left unset: producers that can write anywhere put the gradient straight into the parameter's slot
+        (_grad_slots.take) and autograd adopts it without a kernel; any other gradient is copied into its slot by the
+        post-accumulate hook.  Either way `param.grad` is a view into the flat arena when backward returns."""
         if self._arena is None:
             return
         self._arena.zero_()
         for p in self._order:
-            p.grad = self._views[id(p)] if p.requires_grad else None
+            p.grad = None
+            if p.requires_grad:
+                _grad_slots.register(p, self._views[id(p)])
+            else:
+                _grad_slots.unregister(p)
         self._pending = [0] * len(self._buckets)
         for p in self._order:
             if p.requires_grad:
                 self._pending[self._bucket_of[id(p)]] += 1
         self._handles = []
-        if self.world > 1 and not self._hooks_installed:
+        if not self._hooks_installed:
             for p in self._order:
                 p.register_post_accumulate_grad_hook(self._make_hook(p))
             self._hooks_installed = True
 
     def _make_hook(self, p):
         def hook(param):
+            v = self._views[id(p)]
+            g = param.grad
+            if g is not None and g.data_ptr() != v.data_ptr():  # produced elsewhere: move it into the arena
+                v.copy_(g)
+                param.grad = v
+            if self.world <= 1:
+                return
             b = self._bucket_of[id(p)]
             if b >= len(self._pending):
                 return
@@ -105,7 +122,12 @@ class HipDDP(torch.nn.Module):
 
     def finish(self):
         """Join the bucket all-reduces (also launches buckets whose hooks never fired, e.g. unused parameters)."""
-        if self.world <= 1 or self._arena is None:
+        if self._arena is None:
+            return
+        for p in self._order:  # parameters without a gradient this step keep the old contract: a zero view
+            if p.requires_grad and p.grad is None:
+                p.grad = self._views[id(p)]
+        if self.world <= 1:
             return
         for b, n in enumerate(self._pending):
             if n > 0:

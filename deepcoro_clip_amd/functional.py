@@ -10,6 +10,7 @@ import math
 
 import torch
 
+from . import _grad_slots
 from . import kernels as K
 
 # ------------------------------------------------------------------------------ weight shadows
@@ -143,13 +144,15 @@ def grads_unset(*params) -> bool:
     return all(p is None or (p.is_leaf and p.grad is None) for p in params)  # non-leaf: not ours to reason about
 
 
-def wgrad(g2: torch.Tensor, x2: torch.Tensor, colsum: torch.Tensor | None = None, side: bool = False) -> torch.Tensor:
+def wgrad(g2: torch.Tensor, x2: torch.Tensor, colsum: torch.Tensor | None = None, side: bool = False,
+          out: torch.Tensor | None = None) -> torch.Tensor:
     """dW[n][k] = sum_rows g2[row][n] * x2[row][k] in fp32 (k-major GEMM; split over the row range when the
     n x k output alone cannot fill the chip, accumulating into a pre-zeroed arena slice)."""
     rows, N = g2.shape
     Kd = x2.shape[1]
     sk = K.wgrad_splitk(rows, N, Kd)
-    out = zeros_f32((N, Kd), g2.device) if sk > 1 else torch.empty((N, Kd), device=g2.device, dtype=torch.float32)
+    if out is None:  # `out`: a zeroed gradient slot handed out by the owner of the gradient memory (_grad_slots)
+        out = zeros_f32((N, Kd), g2.device) if sk > 1 else torch.empty((N, Kd), device=g2.device, dtype=torch.float32)
     side = side and WGRAD_SIDE
     if side and not _WG["queued"]:
         try:
@@ -212,8 +215,10 @@ class LinearFn(torch.autograd.Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_db:  # bias gradient rides in the weight-gradient GEMM (column sums of its k-major A operand)
-                db = zeros_f32(N, g.device)
-            dw = wgrad(g, x2, db, side=WGRAD_SIDE and grads_unset(*ctx.params))
+                db = _grad_slots.take(ctx.params[1])
+                if db is None:
+                    db = zeros_f32(N, g.device)
+            dw = wgrad(g, x2, db, side=WGRAD_SIDE and grads_unset(*ctx.params), out=_grad_slots.take(ctx.params[0]))
         elif want_db:
             db = K.colsum(g)
         if ctx.has_res and ctx.needs_input_grad[4]:
@@ -253,14 +258,18 @@ class MlpFn(torch.autograd.Function):
         dw2 = db2 = dw1 = db1 = dx = None
         f32 = dict(device=dy2.device, dtype=torch.float32)
         if ctx.needs_input_grad[3]:
-            db2 = zeros_f32(N, dy2.device) if ctx.needs_input_grad[4] else None
-            dw2 = wgrad(dy2, act, db2, side=WGRAD_SIDE and grads_unset(*ctx.params[2:]))
+            db2 = (_grad_slots.take(ctx.params[3]) if ctx.needs_input_grad[4] else None)
+            if db2 is None and ctx.needs_input_grad[4]:
+                db2 = zeros_f32(N, dy2.device)
+            dw2 = wgrad(dy2, act, db2, side=WGRAD_SIDE and grads_unset(*ctx.params[2:]), out=_grad_slots.take(ctx.params[2]))
         elif ctx.needs_input_grad[4]:
             db2 = K.colsum(dy2)
         dpre = K.gemm(dy2, w2c, b_km=True, dgelu=True, aux=pre)
         if ctx.needs_input_grad[1]:
-            db1 = zeros_f32(Hd, dy2.device) if ctx.needs_input_grad[2] else None
-            dw1 = wgrad(dpre, x2, db1, side=WGRAD_SIDE and grads_unset(*ctx.params[:2]))
+            db1 = (_grad_slots.take(ctx.params[1]) if ctx.needs_input_grad[2] else None)
+            if db1 is None and ctx.needs_input_grad[2]:
+                db1 = zeros_f32(Hd, dy2.device)
+            dw1 = wgrad(dpre, x2, db1, side=WGRAD_SIDE and grads_unset(*ctx.params[:2]), out=_grad_slots.take(ctx.params[0]))
         elif ctx.needs_input_grad[2]:
             db1 = K.colsum(dpre)
         if ctx.needs_input_grad[0]:

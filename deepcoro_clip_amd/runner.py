@@ -123,6 +123,7 @@ class VideoContrastiveLearningRunner:
         if os.environ.get("DCC_STEP_GRAPH") in ("1", "auto"):
             self._use_step_graph = True if os.environ["DCC_STEP_GRAPH"] == "1" else "auto"
         self._graphs: dict = {}
+        self._autograd_mt = os.environ.get("DCC_AUTOGRAD_MT", "0") == "1"  # backward on the engine's device thread
         self._wgrad_side = os.environ.get("DCC_WGRAD_STREAM", "0") == "1"  # measured: +5 ms of host launch time > what it hides
         self._graph_stream: torch.cuda.Stream | None = None
 
@@ -324,7 +325,7 @@ class VideoContrastiveLearningRunner:
             # backward on the calling thread: handing ~670 nodes to the engine's device thread one by one costs the host
             # ~13 % of a step's launch time (31.0 -> 26.9 ms on launch-bound 112^2 inputs), and the host is the limit on
             # boxes with slow cores
-            with torch.autograd.set_multithreading_enabled(False):
+            with torch.autograd.set_multithreading_enabled(self._autograd_mt):
                 total_loss.backward(self._accum_grad)  # == (loss / accum).backward() without an extra kernel
         finally:
             Fn.WGRAD_SIDE = False

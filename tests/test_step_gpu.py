@@ -257,3 +257,35 @@ def test_hip_graph_step_matches_eager_steps():
     for (n, p), (_, q) in zip(eager.text_encoder.named_parameters(), graph.text_encoder.named_parameters()):
         assert torch.allclose(p, q, rtol=1e-3, atol=1e-5), n
     assert eager.step == graph.step == 8
+
+
+def test_ddp_wrapped_step_writes_gradients_into_the_arena_and_matches_plain_steps():
+    """HipDDP (world size 1 here): weight / bias gradients are produced straight in the flat arena (_grad_slots), the rest
+    is moved there by the post-accumulate hook; losses and parameters track the unwrapped runner."""
+    import __graft_entry__ as ge
+    from deepcoro_clip_amd.ddp import HipDDP
+
+    def run(wrap):
+        runner, _, (videos, ids, mask) = ge.make_tiny_setup(torch.float32, seed=5)
+        if wrap:
+            runner.video_encoder, runner.text_encoder = HipDDP(runner.video_encoder), HipDDP(runner.text_encoder)
+        losses = []
+        for _ in range(4):
+            m, _ = runner._train_step(videos=videos.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda())
+            losses.append(m["loss"])
+        torch.cuda.synchronize()
+        return runner, losses
+
+    plain, lp = run(False)
+    ddp, ld = run(True)
+    assert max(abs(a - b) for a, b in zip(lp, ld)) < 2e-4 * max(1.0, max(abs(x) for x in lp)), (lp, ld)
+    te = ddp.text_encoder
+    lo, hi = te._arena.data_ptr(), te._arena.data_ptr() + te._arena.numel() * 4
+    n_in = sum(1 for p in te.module.parameters() if p.grad is not None and lo <= p.grad.data_ptr() < hi)
+    n_all = sum(1 for p in te.module.parameters() if p.requires_grad)
+    assert n_in == n_all, (n_in, n_all)   # every gradient ended up as a view into the flat arena
+    from deepcoro_clip_amd import _grad_slots
+    n_lin = sum(2 for m in te.module.modules() if isinstance(m, torch.nn.Linear))
+    assert len(_grad_slots._TAKEN) >= n_lin, (len(_grad_slots._TAKEN), n_lin)  # Linear weights + biases were written in place
+    for (n, p), (_, q) in zip(plain.text_encoder.named_parameters(), te.module.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-3, atol=1e-5), n
