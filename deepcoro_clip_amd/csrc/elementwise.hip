@@ -322,9 +322,12 @@ __device__ __forceinline__ uint32_t hash32(uint64_t k) {  // splitmix64 finalise
   k ^= k >> 31;
   return (uint32_t)(k >> 32);
 }
-// y = x * keep / (1-p); keep regenerated from (seed, index) so no mask is stored.
+// y = x * keep / (1-p); keep regenerated from (seed, index) so no mask is stored.  `step` (nullable, device): a counter
+// mixed into the seed, so that a launch replayed from a HIP graph draws a new mask whenever the counter was advanced.
 template <typename T>
-__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, uint64_t seed) {
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, uint64_t seed,
+                               const int64_t* __restrict__ step) {
+  if (step) seed += (uint64_t)(*step) * 0x9E3779B97F4A7C15ULL;
   const float scale = 1.0f / (1.0f - p);
   const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -493,11 +496,12 @@ extern "C" int dcc_nan_to_num(void* x, int64_t n, float nanv, float posv, float 
 }
 
 // The same (seed) regenerates the same keep-mask: call with x = dy for the backward.
-extern "C" int dcc_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+extern "C" int dcc_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const int64_t* step, int dtype,
+                           void* stream) {
   if (!x || !y || n <= 0 || p < 0.0f || p >= 1.0f) return DCC_ERR_ARG;
   dim3 g(gs_blocks(n, 4));
-  if (dtype == DCC_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, n, p, seed);
-  else if (dtype == DCC_F32) hipLaunchKernelGGL((dropout_kernel<float>), g, dim3(256), 0, ST, (const float*)x, (float*)y, n, p, seed);
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, n, p, seed, step);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((dropout_kernel<float>), g, dim3(256), 0, ST, (const float*)x, (float*)y, n, p, seed, step);
   else return DCC_ERR_UNSUPPORTED;
   return dcc_check_launch();
 }

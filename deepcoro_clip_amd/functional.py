@@ -737,17 +737,26 @@ def cast(x, dtype):
 
 
 _DROPOUT_CALLS = 0
+# Training-step scope (set by the runner): inside it a dropout call's seed is (base seed, position of the call within the
+# step) on the host plus a DEVICE step counter the kernel mixes in — nothing per-step is baked into the launch arguments,
+# so a step captured in a HIP graph draws new masks at every replay (the runner advances the counter inside the graph).
+_STEP = {"counter": None, "calls": 0}
+
+
+def begin_step(counter: torch.Tensor | None) -> None:
+    """counter: device int64 [1] advanced once per step by the caller, or None to leave the step scope."""
+    _STEP["counter"], _STEP["calls"] = counter, 0
 
 
 class DropoutFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, seed):
-        ctx.p, ctx.seed = p, seed
-        return K.dropout(_c(x), p, seed)
+    def forward(ctx, x, p, seed, step):
+        ctx.p, ctx.seed, ctx.step = p, seed, step
+        return K.dropout(_c(x), p, seed, step)
 
     @staticmethod
     def backward(ctx, d):
-        return K.dropout(_c(d), ctx.p, ctx.seed), None, None
+        return K.dropout(_c(d), ctx.p, ctx.seed, ctx.step), None, None, None
 
 
 def dropout(x, p: float, training: bool):
@@ -755,9 +764,14 @@ def dropout(x, p: float, training: bool):
     global _DROPOUT_CALLS
     if not training or p <= 0.0:
         return x
+    step = _STEP["counter"]
+    if step is not None and step.device == x.device:
+        _STEP["calls"] += 1
+        seed = (torch.initial_seed() * 1000003 + _STEP["calls"]) & (2**63 - 1)
+        return DropoutFn.apply(x, float(p), seed, step)
     _DROPOUT_CALLS += 1
     seed = (torch.initial_seed() * 1000003 + _DROPOUT_CALLS) & (2**63 - 1)
-    return DropoutFn.apply(x, float(p), seed)
+    return DropoutFn.apply(x, float(p), seed, None)
 
 
 class EmbedFn(torch.autograd.Function):

@@ -546,11 +546,12 @@ def nan_to_num_(x: torch.Tensor, nan: float = 0.0, posinf: float = 0.0, neginf: 
     return x
 
 
-def dropout(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
-    L.require_cuda(x)
-    assert x.is_contiguous()
+def dropout(x: torch.Tensor, p: float, seed: int, step: torch.Tensor | None = None) -> torch.Tensor:
+    """`step`: device int64 counter mixed into the seed (a HIP-graph replay then draws fresh masks when it advanced)."""
+    L.require_cuda(x, step)
+    assert x.is_contiguous() and (step is None or (step.dtype == torch.int64 and step.numel() == 1))
     out = torch.empty_like(x)
-    L.call("dcc_dropout", L.ptr(x), L.ptr(out), x.numel(), float(p), ctypes.c_uint64(seed & (2**64 - 1)), L.dt(x),
+    L.call("dcc_dropout", L.ptr(x), L.ptr(out), x.numel(), float(p), ctypes.c_uint64(seed & (2**64 - 1)), L.ptr(step), L.dt(x),
            L.stream())
     return out
 

@@ -123,6 +123,7 @@ class VideoContrastiveLearningRunner:
         if os.environ.get("DCC_STEP_GRAPH") in ("1", "auto"):
             self._use_step_graph = True if os.environ["DCC_STEP_GRAPH"] == "1" else "auto"
         self._graphs: dict = {}
+        self._dropout_step: torch.Tensor | None = None
         self._autograd_mt = os.environ.get("DCC_AUTOGRAD_MT", "0") == "1"  # backward on the engine's device thread
         self._wgrad_side = os.environ.get("DCC_WGRAD_STREAM", "0") == "1"  # measured: +5 ms of host launch time > what it hides
         self._graph_stream: torch.cuda.Stream | None = None
@@ -312,7 +313,15 @@ class VideoContrastiveLearningRunner:
     def _forward_backward(self, videos, input_ids, attention_mask, positive_mask, positive_weights, text_metadata, accum):
         if self.step % accum == 0:
             self._zero_grad()
-        video_emb, text_emb = self._encode(videos, input_ids, attention_mask)
+        # dropout masks: device-side step counter (advanced here, inside a captured step too) + per-call host seeds
+        if self._dropout_step is None or self._dropout_step.device != videos.device:
+            self._dropout_step = torch.zeros(1, device=videos.device, dtype=torch.int64)
+        self._dropout_step.add_(1)
+        Fn.begin_step(self._dropout_step)
+        try:
+            video_emb, text_emb = self._encode(videos, input_ids, attention_mask)
+        finally:
+            Fn.begin_step(None)
         diag: dict = {}
         clip_loss = self._loss(video_emb, text_emb, positive_mask, positive_weights, text_metadata, diag)
         total_loss = clip_loss
@@ -438,7 +447,7 @@ class VideoContrastiveLearningRunner:
                     if t is not None:
                         t.record_stream(side)
                 if Fn._DROPOUT_CALLS != drops:
-                    st["eager_only"] = True   # host-seeded dropout masks would be frozen into the graph
+                    st["eager_only"] = True   # a dropout call outside the step scope: its host seed would be frozen
                 return res
             st["inputs"] = [None if t is None else t.clone() for t in (videos, input_ids, attention_mask)]
             gc.collect()

@@ -149,7 +149,9 @@ int dcc_qpool_bwd(const float* x, const float* q, const float* w, const float* d
                   int N, int D, void* stream);
 /* torch.nan_to_num guards (runners/video_constrative_learning_runner.py:1189,1236-1238) */
 int dcc_nan_to_num(void* x, int64_t n, float nanv, float posv, float negv, int* count, int dtype, void* stream);
-int dcc_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* nn.Dropout: keep mask = hash(seed [+ *step * golden ratio], index); `step` (nullable, device int64) lets a captured launch
+ * draw a new mask per replay; the same (seed, *step) regenerates the mask for the backward. */
+int dcc_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const int64_t* step, int dtype, void* stream);
 int dcc_scale_by_dev(float* x, int64_t n, const float* coef, void* stream);
 
 /* ---- contrastive losses (csrc/loss.hip); scal = fp32[8]

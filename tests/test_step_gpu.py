@@ -230,14 +230,17 @@ def test_step_metrics_resolve_lazily_with_reference_keys():
     assert emb["video_embeddings"].shape == (2, 512) and emb["text_embeddings"].shape == (2, 512)
 
 
-def test_hip_graph_step_matches_eager_steps():
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+def test_hip_graph_step_matches_eager_steps(p_drop):
     """Opt-in HIP-graph replay of forward + loss + backward + clip (runner._graph_train_step): same losses and parameters
-    as the eager step on changing batches; warm-up calls run eagerly, the 4th call captures."""
+    as the eager step on changing batches; warm-up calls run eagerly, the 4th call captures.  With dropout the masks come
+    from (host seed of the call site, DEVICE step counter), so a replay draws the masks the eager step would draw."""
     import __graft_entry__ as ge
 
     def run(use_graph):
         runner, _, (videos, ids, mask) = ge.make_tiny_setup(torch.float32, seed=3)
         runner._use_step_graph = use_graph
+        runner.video_encoder.dropout = p_drop
         g = torch.Generator().manual_seed(11)
         losses = []
         for i in range(8):
