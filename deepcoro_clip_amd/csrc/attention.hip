@@ -312,11 +312,29 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
   for (int s = 0; s < DQK / 16; ++s) qf[s] = gfrag<T>(Q, p.sqn, myq, p.Nq, s, h);
 #pragma unroll
   for (int s = 0; s < DV / 16; ++s) dof[s] = gfrag<T>(dO, p.son, myq, p.Nq, s, h);
+  // D[q] = sum_d dO[q][d] * (O[q][d] - [q >= res_start] Qres[q][d]): the rows are already here as fragments (the residual
+  // shortcut adds the pooled query, i.e. the first DV columns of this Q row), so the separate preparation kernel is gone;
+  // the value is also stored for the dK/dV kernel, which runs after this one on the same stream.
   float lse2 = INFINITY, dv = 0.0f;
+  {
+    const T* O = reinterpret_cast<const T*>(p.O) + b * p.sob + hd * p.soh;
+    const bool res = p.Qres != nullptr && myq >= p.res_start;
+    const bool same = p.Qres == p.Q;  // the usual case: the residual is the pooled query itself
+    const T* QR = reinterpret_cast<const T*>(p.Qres) + b * p.sqb + hd * p.sqh;
+#pragma unroll
+    for (int s = 0; s < DV / 16; ++s) {
+      const frag_t<T> of = gfrag<T>(O, p.son, myq, p.Nq, s, h);
+      frag_t<T> rf = qf[s < DQK / 16 ? s : 0];
+      if (res && !same) rf = gfrag<T>(QR, p.sqn, myq, p.Nq, s, h);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dv += to_f32(dof[s][e]) * (to_f32(of[e]) - (res ? to_f32(rf[e]) : 0.0f));
+    }
+    dv += xhalf(dv);
+  }
   if (myq < p.Nq) {
     const int64_t o = ((int64_t)b * p.H + hd) * p.Nq + myq;
     lse2 = p.LSE[o] * LOG2E;
-    dv = p.Dv[o];
+    if (h == 0) const_cast<float*>(p.Dv)[o] = dv;
   }
   f32x16 dq[DQK / 32];
 #pragma unroll
@@ -534,43 +552,6 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
-// Dv[b,h,q] = sum_d dO[q][d] * (O[q][d] - [q >= res_start] Qres[q][d]).  16 lanes per (b,h,q) row, 16-byte chunks
-// (rows are 96..128 wide: 12..16 lanes carry data), folded with four shuffles.
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnParams p, int DV) {
-  constexpr int VEC = Vec16<T>::N;
-  using V = vec16_t<T>;
-  const int sub = threadIdx.x & 15;
-  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int64_t total = (int64_t)p.B * p.H * p.Nq;
-  float acc = 0.0f;
-  if (row < total) {
-    const int q = row % p.Nq;
-    const int hd = (row / p.Nq) % p.H;
-    const int b = row / ((int64_t)p.Nq * p.H);
-    const T* o = reinterpret_cast<const T*>(p.O) + b * p.sob + hd * p.soh + (int64_t)q * p.son;
-    const T* d = reinterpret_cast<const T*>(p.dO) + b * p.sob + hd * p.soh + (int64_t)q * p.son;
-    const T* r = (p.Qres && q >= p.res_start)
-                     ? reinterpret_cast<const T*>(p.Qres) + b * p.sqb + hd * p.sqh + (int64_t)q * p.sqn
-                     : nullptr;
-    for (int c = sub * VEC; c < DV; c += 16 * VEC) {
-      const V ov = *reinterpret_cast<const V*>(o + c);
-      const V dv = *reinterpret_cast<const V*>(d + c);
-      if (r) {
-        const V rv = *reinterpret_cast<const V*>(r + c);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) acc += to_f32(dv[e]) * (to_f32(ov[e]) - to_f32(rv[e]));
-      } else {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) acc += to_f32(dv[e]) * to_f32(ov[e]);
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if (sub == 0 && row < total) const_cast<float*>(p.Dv)[row] = acc;
-}
-
 template <typename T, int DQK, int DV>
 int launch_attn(int which, const AttnParams& p, int out_f32, hipStream_t st) {
   if (which == 0) {
@@ -653,13 +634,7 @@ extern "C" int dcc_attn_bwd(const void* Q, const void* K, const void* V, const v
   for (int i = 12; i < 21; ++i)
     if (strides[i] % 4) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t rows = (int64_t)B * H * Nq;
-  dim3 pg((unsigned)((rows + 15) / 16));
-  if (dtype == DCC_BF16) hipLaunchKernelGGL((attn_bwd_prep_kernel<bf16_t>), pg, dim3(256), 0, st, p, DV);
-  else if (dtype == DCC_F32) hipLaunchKernelGGL((attn_bwd_prep_kernel<float>), pg, dim3(256), 0, st, p, DV);
-  else return DCC_ERR_UNSUPPORTED;
-  rc = dcc_check_launch();
-  if (rc) return rc;
+  if (dtype != DCC_BF16 && dtype != DCC_F32) return DCC_ERR_UNSUPPORTED;
   const int out_f32 = (qsplit > 1) || dtype == DCC_F32;
   for (int which = 1; which <= 2; ++which) {
     if (dtype == DCC_BF16) rc = dispatch_dims<bf16_t>(which, p, DQK, DV, out_f32, st);
