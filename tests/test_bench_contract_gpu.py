@@ -1,0 +1,32 @@
+"""bench.py's output contract (one JSON line on stdout with the fields the driver reads), exercised on a small geometry."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "2",
+           "--frames", "4", "--size", "64", "--seq", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["scaling"] == "weak" and out["vs_baseline"] is None and out["dtype"] == "bf16" and out["data"] == "synthetic"
+    assert out["value"] > 0 and abs(out["value"] - 2 / (out["ms_per_step"] * 1e-3)) < 1e-2 * out["value"]
+    assert "workload" in out["config"] and "model" not in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = out["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"] and cb["unit"]
