@@ -30,3 +30,21 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = out["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"] and cb["unit"]
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The N > 1 launch path (torch.distributed.run, one process per rank, HipDDP arena + bucketed all-reduce, global
+    loss over gathered embeddings) rehearsed with two ranks sharing this GPU over gloo (RCCL needs one GPU per rank)."""
+    env = dict(os.environ, DCC_BENCH_BACKEND="gloo", DCC_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
+           "--frames", "4", "--size", "64", "--seq", "16", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["global_batch"] == 4 and out["value"] > 0
+    import math
+    assert abs(out["config"]["loss_first"] - math.log(4)) < 0.2  # InfoNCE over the GLOBAL 4 x 4 similarity matrix at init
