@@ -534,7 +534,6 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
               *reinterpret_cast<bf16x4*>(rowp + 16 * g4) = o;
             }
           }
-        zero_acc();
         pending = false;
         PROF_ADD(2, PROF_T() - tb1);
       }
@@ -556,10 +555,18 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
         if (s + 1 < BK / 16) fetch(cur ^ 1, s + 1);
         __builtin_amdgcn_sched_barrier(0);
         // swapped operands: the accumulator tile is C^T (rows = n on registers, columns = m on lanes)
+        if (s == 0 && kt == 0) {  // first MFMA of a tile starts from C = 0 (inline constant): no 64 v_mov to clear acc
+          const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fb[cur][j], fa[cur][i], acc[i][j]);
+            for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fb[cur][j], fa[cur][i], zero);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fb[cur][j], fa[cur][i], acc[i][j]);
+        }
       }
       if (++kt == nk) {
         kt = 0;
