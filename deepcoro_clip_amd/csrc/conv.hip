@@ -1282,7 +1282,7 @@ extern "C" int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 1 && g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 2 && g.sw == 2 && g.pt == 0 && g.ph == 1 &&
-      g.pw == 1 && (g.C / vec) <= 64 && (int64_t)g.B * g.H * g.T * g.Hs * g.Ws < (1 << 25)) {
+      g.pw == 1 && (g.C / vec) <= 128 && (int64_t)g.B * g.H * g.T * g.Hs * g.Ws < (1 << 25)) {
     const RunGeom r = make_run_geom(g, vec, 4);
     const int items = g.B * g.H * g.T * g.Hs * g.Ws + (g.has_cls ? g.B * g.H : 0);
     const dim3 grid((items + r.slots - 1) / r.slots);
