@@ -26,6 +26,12 @@ struct RelGeom {
   int64_t sb, sn, sh;    // strides of the Qf-like operand (b, token, head)
 };
 
+// multiply-shift division by launch constants (exact for n < 2^40 / d; rows stay far below)
+struct FastDiv { unsigned d; unsigned long long m; };
+inline FastDiv mkdiv(unsigned d) { FastDiv f; f.d = d ? d : 1; f.m = ((1ull << 40) / f.d) + 1; return f; }
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return (unsigned)(((unsigned long long)n * f.m) >> 40); }
+struct RelDiv { FastDiv H, Nq, plane, qw, cl, ca; };
+
 template <typename T> __device__ __forceinline__ void store8(T* dst, const float* v) {
   if constexpr (sizeof(T) == 2) {
     bf16x8 o;
@@ -43,25 +49,25 @@ template <typename T> __device__ __forceinline__ void store8(T* dst, const float
 template <typename T>
 __global__ __launch_bounds__(256) void relpos_gather_kernel(T* __restrict__ Qf, const T* __restrict__ P,
                                                             const int* __restrict__ idx_h, const int* __restrict__ idx_w,
-                                                            const int* __restrict__ idx_t, RelGeom g, float inv_scale) {
+                                                            const int* __restrict__ idx_t, RelGeom g, RelDiv dv, float inv_scale) {
   const int Nq = g.qt * g.qh * g.qw + g.has_cls;
   const int cpr = g.A / 8;  // A is a multiple of 32
   const unsigned total = (unsigned)g.B * Nq * g.H * cpr;
   const unsigned id = blockIdx.x * 256u + threadIdx.x;
   if (id >= total) return;
-  const unsigned row = id / cpr;  // (b, n, head) row of P
+  const unsigned row = fdiv(id, dv.ca);  // (b, n, head) row of P
   const int j0 = (id - row * cpr) * 8;
-  const unsigned bn = row / g.H;
+  const unsigned bn = fdiv(row, dv.H);
   const int hd = row - bn * g.H;
-  const unsigned b = bn / Nq;
+  const unsigned b = fdiv(bn, dv.Nq);
   const int n = bn - b * Nq;
   // Branch-free: the 8 table lookups are issued together, then the 8 gathers (an if-chain with a load in every arm made
   // the compiler wait for each load inside its branch: 16 serialised round trips per thread).
   float v[8];
   const bool tokrow = !(g.has_cls && n == 0);
   const int i = tokrow ? n - g.has_cls : 0;
-  const int t = i / (g.qw * g.qh), r = i - t * (g.qw * g.qh);
-  const int hh = r / g.qw, w = r - hh * g.qw;
+  const int t = fdiv(i, dv.plane), r = i - t * (g.qw * g.qh);
+  const int hh = fdiv(r, dv.qw), w = r - hh * g.qw;
   const T* prow = P + (int64_t)row * g.L;
   int l[8];
   bool ok[8];
@@ -122,24 +128,102 @@ __global__ __launch_bounds__(256) void relpos_scatter_kernel(const T* __restrict
   store8<T>(dP + (int64_t)row * g.L + l0, v);
 }
 
-// one-hot key augmentation, one thread per (b, n, head, j)
-template <typename T>
-__global__ void relpos_kaug_kernel(T* __restrict__ Kf, RelGeom g) {
-  const int Nk = g.kt * g.kh * g.kw + g.has_cls;
-  const int64_t total = (int64_t)g.B * Nk * g.H * g.A;
-  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
-    const int j = id % g.A;
-    const int hd = (id / g.A) % g.H;
-    const int n = (id / ((int64_t)g.A * g.H)) % Nk;
-    const int b = id / ((int64_t)g.A * g.H * Nk);
-    float v = 0.0f;
-    if (!(g.has_cls && n == 0)) {
-      const int i = n - g.has_cls;
-      const int w = i % g.kw, hh = (i / g.kw) % g.kh, t = i / (g.kw * g.kh);
-      if (j == hh || j == g.kh + w || j == g.kh + g.kw + t) v = 1.0f;
-    }
-    Kf[b * g.sb + (int64_t)n * g.sn + hd * g.sh + g.D + j] = from_f32<T>(v);
+// LDS-staged scatter: a block owns RPB rows.  The three inverse tables (a few KB) and the rows' augmentation columns are
+// staged in LDS once, so a thread's 8 lookups + 8 picks are LDS reads (the direct version issues 16 dependent global
+// loads per 16 bytes of output and runs at ~1 TB/s).
+constexpr int RPB = 32;
+template <typename T, bool STAGE_TABLES>
+__global__ __launch_bounds__(256) void relpos_scatter_lds_kernel(const T* __restrict__ dQf, T* __restrict__ dP,
+                                                                 const int* __restrict__ inv_h, const int* __restrict__ inv_w,
+                                                                 const int* __restrict__ inv_t, RelGeom g, RelDiv dv, float inv_scale) {
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  const int nh = g.qh * g.Lh, nw = g.qw * g.Lw, nt = g.qt * g.Lt;
+  // small tables (the 14x14 / 7x7 stages: < 8 KB) are staged too; the 56x56 stage's 50 KB stay in global memory / L1
+  const int* th = inv_h; const int* tw = inv_w; const int* tt = inv_t;
+  T* aug = reinterpret_cast<T*>(lds_i);   // [RPB][A]
+  if constexpr (STAGE_TABLES) {
+    int* sh_ = lds_i; int* sw_ = sh_ + nh; int* st_ = sw_ + nw;
+    aug = reinterpret_cast<T*>(lds_i + ((nh + nw + nt + 3) & ~3));
+    for (int i = threadIdx.x; i < nh; i += 256) sh_[i] = inv_h[i];
+    for (int i = threadIdx.x; i < nw; i += 256) sw_[i] = inv_w[i];
+    for (int i = threadIdx.x; i < nt; i += 256) st_[i] = inv_t[i];
+    th = sh_; tw = sw_; tt = st_;
   }
+  const int Nq = g.qt * g.qh * g.qw + g.has_cls;
+  const unsigned rows = (unsigned)g.B * Nq * g.H;
+  const unsigned row0 = blockIdx.x * RPB;
+  const int ca = g.A / 8;
+  for (int i = threadIdx.x; i < RPB * ca; i += 256) {
+    const unsigned lr = fdiv(i, dv.ca), c = i - lr * ca, row = row0 + lr;
+    if (row < rows) {
+      const unsigned bn = fdiv(row, dv.H);
+      const int hd = row - bn * g.H;
+      const unsigned b = fdiv(bn, dv.Nq);
+      const int n = bn - b * Nq;
+      const T* src = dQf + b * g.sb + (int64_t)n * g.sn + hd * g.sh + g.D + c * 8;
+      if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x8*>(aug + lr * g.A + c * 8) = *reinterpret_cast<const bf16x8*>(src);
+      else {
+        *reinterpret_cast<f32x4*>(aug + lr * g.A + c * 8) = *reinterpret_cast<const f32x4*>(src);
+        *reinterpret_cast<f32x4*>(aug + lr * g.A + c * 8 + 4) = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+    }
+  }
+  __syncthreads();
+  const int cl = g.L / 8;
+  for (int i = threadIdx.x; i < RPB * cl; i += 256) {
+    const unsigned lr = fdiv(i, dv.cl), row = row0 + lr;
+    if (row >= rows) break;
+    const int l0 = (i - lr * cl) * 8;
+    const unsigned bn = fdiv(row, dv.H);
+    const unsigned b = fdiv(bn, dv.Nq);
+    const int n = bn - b * Nq;
+    float v[8];
+    const bool tokrow = !(g.has_cls && n == 0);
+    const int p = tokrow ? n - g.has_cls : 0;
+    const int t = fdiv(p, dv.plane), r = p - t * (g.qw * g.qh);
+    const int hh = fdiv(r, dv.qw), w = r - hh * g.qw;
+    const T* arow = aug + lr * g.A;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int l = l0 + e;
+      const bool ok = tokrow && l < g.Lh + g.Lw + g.Lt;
+      const int ax = (l >= g.Lh) + (l >= g.Lh + g.Lw);
+      const int* tp = ax == 0 ? th : (ax == 1 ? tw : tt);
+      const int off = ax == 0 ? hh * g.Lh + l : (ax == 1 ? w * g.Lw + (l - g.Lh) : t * g.Lt + (l - g.Lh - g.Lw));
+      const int jj = tp[ok ? off : 0];
+      const int j = (ok && jj >= 0) ? jj + (ax == 0 ? 0 : (ax == 1 ? g.kh : g.kh + g.kw)) : -1;
+      v[e] = j >= 0 ? to_f32(arow[j]) * inv_scale : 0.0f;
+    }
+    store8<T>(dP + (int64_t)row * g.L + l0, v);
+  }
+}
+
+// one-hot key augmentation: one thread = 8 columns of one (b, n, head) row (a 16-byte store), 32-bit index arithmetic
+// with multiply-shift divisions (the first version spent ~100 instructions per ELEMENT on 64-bit div / mod).
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_kaug_kernel(T* __restrict__ Kf, RelGeom g, RelDiv dv) {
+  const int Nk = g.kt * g.kh * g.kw + g.has_cls;
+  const int ca = g.A / 8;
+  const unsigned total = (unsigned)g.B * Nk * g.H * ca;
+  const unsigned id = blockIdx.x * 256u + threadIdx.x;
+  if (id >= total) return;
+  const unsigned row = fdiv(id, dv.ca);
+  const int j0 = (id - row * ca) * 8;
+  const unsigned bn = fdiv(row, dv.H);
+  const int hd = row - bn * g.H;
+  const unsigned b = fdiv(bn, dv.Nq);   // dv.Nq / plane / qw are built from the KEY grid for this kernel
+  const int n = bn - b * Nk;
+  float v[8];
+  const bool tok = !(g.has_cls && n == 0);
+  const int i = tok ? n - g.has_cls : 0;
+  const int t = fdiv(i, dv.plane), r = i - t * (g.kw * g.kh);
+  const int hh = fdiv(r, dv.qw), w = r - hh * g.kw;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int j = j0 + e;
+    v[e] = (tok && (j == hh || j == g.kh + w || j == g.kh + g.kw + t)) ? 1.0f : 0.0f;
+  }
+  store8<T>(Kf + b * g.sb + (int64_t)n * g.sn + hd * g.sh + g.D + j0, v);
 }
 
 inline unsigned gsb(int64_t n) {
@@ -171,8 +255,9 @@ extern "C" int dcc_relpos_gather(void* Qf, const void* P, const int* idx_h, cons
   const int64_t total = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H * (g.A / 8);
   if (total >= (1LL << 31)) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DCC_BF16) hipLaunchKernelGGL((relpos_gather_kernel<bf16_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (bf16_t*)Qf, (const bf16_t*)P, idx_h, idx_w, idx_t, g, 1.0f / scale);
-  else if (dtype == DCC_F32) hipLaunchKernelGGL((relpos_gather_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (float*)Qf, (const float*)P, idx_h, idx_w, idx_t, g, 1.0f / scale);
+  const RelDiv dv{mkdiv(g.H), mkdiv(g.qt * g.qh * g.qw + g.has_cls), mkdiv(g.qw * g.qh), mkdiv(g.qw), mkdiv(g.L / 8), mkdiv(g.A / 8)};
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((relpos_gather_kernel<bf16_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (bf16_t*)Qf, (const bf16_t*)P, idx_h, idx_w, idx_t, g, dv, 1.0f / scale);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((relpos_gather_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (float*)Qf, (const float*)P, idx_h, idx_w, idx_t, g, dv, 1.0f / scale);
   else return DCC_ERR_UNSUPPORTED;
   return dcc_check_launch();
 }
@@ -186,6 +271,23 @@ extern "C" int dcc_relpos_scatter(const void* dQf, void* dP, const int* inv_h, c
   const int64_t total = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H * (g.L / 8);
   if (total >= (1LL << 31)) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  {
+    const int esz = dtype == DCC_BF16 ? 2 : 4;
+    const int ntab = g.qh * g.Lh + g.qw * g.Lw + g.qt * g.Lt;
+    const bool stage = ntab <= 2048;
+    const size_t lds = (stage ? (size_t)((ntab + 3) & ~3) * 4 : 0) + (size_t)RPB * g.A * esz;
+    const int64_t rows = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H;
+    static const bool use_lds = !getenv("DCC_RELPOS_NO_LDS");
+    if (use_lds && g.kh + g.kw + g.kt <= g.A && rows < (1LL << 31) && (dtype == DCC_BF16 || dtype == DCC_F32)) {
+      const dim3 grid((unsigned)((rows + RPB - 1) / RPB));
+      RelDiv dv{mkdiv(g.H), mkdiv(g.qt * g.qh * g.qw + g.has_cls), mkdiv(g.qw * g.qh), mkdiv(g.qw), mkdiv(g.L / 8), mkdiv(g.A / 8)};
+#define RPS(T_, ST_) hipLaunchKernelGGL((relpos_scatter_lds_kernel<T_, ST_>), grid, dim3(256), lds, st, (const T_*)dQf, (T_*)dP, inv_h, inv_w, inv_t, g, dv, 1.0f / scale)
+      if (dtype == DCC_BF16) { if (stage) RPS(bf16_t, true); else RPS(bf16_t, false); }
+      else { if (stage) RPS(float, true); else RPS(float, false); }
+#undef RPS
+      return dcc_check_launch();
+    }
+  }
   if (dtype == DCC_BF16) hipLaunchKernelGGL((relpos_scatter_kernel<bf16_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)dQf, (bf16_t*)dP, inv_h, inv_w, inv_t, g, 1.0f / scale);
   else if (dtype == DCC_F32) hipLaunchKernelGGL((relpos_scatter_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)dQf, (float*)dP, inv_h, inv_w, inv_t, g, 1.0f / scale);
   else return DCC_ERR_UNSUPPORTED;
@@ -196,10 +298,14 @@ extern "C" int dcc_relpos_scatter(const void* dQf, void* dP, const int* inv_h, c
 extern "C" int dcc_relpos_kaug(void* Kf, const int* dims, const int64_t* strides, int dtype, void* stream) {
   if (!Kf || !dims || !strides) return DCC_ERR_ARG;
   RelGeom g = mk(dims, strides);
-  const int64_t total = (int64_t)g.B * (g.kt * g.kh * g.kw + g.has_cls) * g.H * g.A;
+  if (g.A % 8) return DCC_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)g.B * (g.kt * g.kh * g.kw + g.has_cls) * g.H * (g.A / 8);
+  if (total >= (1LL << 31)) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DCC_BF16) hipLaunchKernelGGL((relpos_kaug_kernel<bf16_t>), dim3(gsb(total)), dim3(256), 0, st, (bf16_t*)Kf, g);
-  else if (dtype == DCC_F32) hipLaunchKernelGGL((relpos_kaug_kernel<float>), dim3(gsb(total)), dim3(256), 0, st, (float*)Kf, g);
+  const RelDiv dv{mkdiv(g.H), mkdiv(g.kt * g.kh * g.kw + g.has_cls), mkdiv(g.kw * g.kh), mkdiv(g.kw), mkdiv(1), mkdiv(g.A / 8)};
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((relpos_kaug_kernel<bf16_t>), grid, dim3(256), 0, st, (bf16_t*)Kf, g, dv);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((relpos_kaug_kernel<float>), grid, dim3(256), 0, st, (float*)Kf, g, dv);
   else return DCC_ERR_UNSUPPORTED;
   return dcc_check_launch();
 }
