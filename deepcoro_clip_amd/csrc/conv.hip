@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void dwconv_reduce_kernel(const float* __restr
 struct RunGeom {
   PoolGeom g;
   int runsW, runs, cpr, slots;
-  FastDiv d_cpr, d_runsW, d_Ho, d_To, d_H, d_Ws, d_Hs, d_T;
+  FastDiv d_cpr, d_runsW, d_Ho, d_To, d_H, d_Ws, d_Hs, d_T, d_Wo;
   // buffer addressing of the stencil input ("x" side) and of dy ("y" side): spans and strides in BYTES (32-bit)
   unsigned xspan, bxb, bxn, bxh;
   unsigned yspan, byb, byn, byh;
@@ -854,6 +854,89 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_wide_kernel(const TD* __rest
     for (int col = S * g.Wo - 1; col < g.Ws; ++col) store_cv<T, CV>(xrow + (int64_t)col * g.sxn, zero);
 }
 
+// skip-path max pool forward: MaxPool3d k(1,3,3) s(1,2,2) p(0,1,1), one thread per output position chunk; the 9 taps
+// are read with unconditional buffer loads (padding taps masked to -inf afterwards), argmax = first maximum in tap order
+// like the generic kernel (which walks them behind three nested bounds branches with 64-bit index arithmetic).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_s2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                             uint8_t* __restrict__ argmax, RunGeom r) {
+  constexpr int CV = Vec16<T>::N;
+  const PoolGeom& g = r.g;
+  const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
+  const int c = threadIdx.x - rs * r.cpr;
+  if ((int)rs >= r.slots) return;
+  const unsigned id = blockIdx.x * r.slots + rs;
+  const int npos = g.B * g.H * g.To * g.Ho * g.Wo;
+  const int No = g.To * g.Ho * g.Wo + g.has_cls;
+  if ((int)id >= npos) {
+    const int i = id - npos;
+    if (g.has_cls && i < g.B * g.H) {
+      const int b = i / g.H, hd = i - b * g.H;
+      float f[CV];
+      load_cv<T, CV>(x + b * g.sxb + hd * g.sxh + c * CV, f);
+      store_cv<T, CV>(y + b * g.syb + hd * g.syh + c * CV, f);
+      if (argmax) {
+        uint8_t* am = argmax + ((((int64_t)b * No) * g.H + hd) * g.C + c * CV);
+#pragma unroll
+        for (int e = 0; e < CV; ++e) am[e] = 255;
+      }
+    }
+    return;
+  }
+  const unsigned t1 = fdiv(id, r.d_Wo);
+  const int wo = id - t1 * g.Wo;
+  const unsigned t2 = fdiv(t1, r.d_Ho);
+  const int ho = t1 - t2 * g.Ho;
+  const unsigned t3 = fdiv(t2, r.d_To);
+  const int to = t2 - t3 * g.To;
+  const unsigned b = fdiv(t3, r.d_H);
+  const int hd = t3 - b * g.H;
+  const __amdgpu_buffer_rsrc_t rsx = span_rsrc(x, r.xspan);
+  const unsigned xbase = b * r.bxb + hd * r.bxh + c * (CV * (unsigned)sizeof(T));
+  RawCV<T, CV> raw[9];
+  bool ok[9];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hh = 2 * ho - 1 + kh;
+    const bool rok = hh >= 0 && hh < g.Hs;
+    const unsigned row = rok ? xbase + (unsigned)(g.has_cls + (to * g.Hs + hh) * g.Ws) * r.bxn : OOB;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ww = 2 * wo - 1 + kw;
+      ok[kh * 3 + kw] = rok && ww >= 0 && ww < g.Ws;
+      raw[kh * 3 + kw] = load_raw_buf<T, CV>(rsx, sat_add(row, (ww >= 0 && ww < g.Ws) ? (unsigned)ww * r.bxn : OOB));
+    }
+  }
+  float acc[CV];
+  int am[CV];
+#pragma unroll
+  for (int e = 0; e < CV; ++e) { acc[e] = -INFINITY; am[e] = 255; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    float f[CV];
+    raw_to_f32<T, CV>(raw[k], f);
+#pragma unroll
+    for (int e = 0; e < CV; ++e) {
+      const bool better = ok[k] && f[e] > acc[e];
+      acc[e] = better ? f[e] : acc[e];
+      am[e] = better ? k : am[e];
+    }
+  }
+  const int n = g.has_cls + (to * g.Ho + ho) * g.Wo + wo;
+  store_cv<T, CV>(y + b * g.syb + (int64_t)n * g.syn + hd * g.syh + c * CV, acc);
+  if (argmax) {
+    uint8_t* amp = argmax + ((((int64_t)b * No + n) * g.H + hd) * g.C + c * CV);
+    if constexpr (CV == 8) {
+      u32x2 pk;
+      pk[0] = (unsigned)am[0] | ((unsigned)am[1] << 8) | ((unsigned)am[2] << 16) | ((unsigned)am[3] << 24);
+      pk[1] = (unsigned)am[4] | ((unsigned)am[5] << 8) | ((unsigned)am[6] << 16) | ((unsigned)am[7] << 24);
+      *reinterpret_cast<u32x2*>(amp) = pk;
+    } else {
+      *reinterpret_cast<uint32_t*>(amp) = (unsigned)am[0] | ((unsigned)am[1] << 8) | ((unsigned)am[2] << 16) | ((unsigned)am[3] << 24);
+    }
+  }
+}
+
 // skip-path max-pool data gradient: MaxPool3d k(1,3,3) s(1,2,2) p(0,1,1) with the argmax recorded by the forward
 // (tap = kh * 3 + kw).  One thread per input position chunk; the <= 2 x 2 windows that contain the position are
 // enumerated exactly (the generic kernel tests all 9 taps with 64-bit index arithmetic).
@@ -1118,7 +1201,7 @@ RunGeom make_run_geom(const PoolGeom& g, int vec, int WT) {
   r.runsW = (g.Wo + WT - 1) / WT;
   r.runs = g.B * g.H * g.To * g.Ho * r.runsW;
   r.d_cpr = mkdiv(r.cpr); r.d_runsW = mkdiv(r.runsW); r.d_Ho = mkdiv(g.Ho); r.d_To = mkdiv(g.To); r.d_H = mkdiv(g.H);
-  r.d_Ws = mkdiv(g.Ws); r.d_Hs = mkdiv(g.Hs); r.d_T = mkdiv(g.T);
+  r.d_Ws = mkdiv(g.Ws); r.d_Hs = mkdiv(g.Hs); r.d_T = mkdiv(g.T); r.d_Wo = mkdiv(g.Wo);
   r.xspan = r.yspan = 0; r.bxb = r.bxn = r.bxh = r.byb = r.byn = r.byh = 0;
   return r;
 }
@@ -1258,6 +1341,18 @@ extern "C" int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* arg
     if (S >= 1 && S <= smax && dtype == DCC_BF16) rr = launch_dw3_run_s<bf16_t, bf16_t, false>(S, x, y, w, g, s);
     else if (S >= 1 && S <= smax && dtype == DCC_F32) rr = launch_dw3_run_s<float, float, false>(S, x, y, w, g, s);
     if (rr != DCC_ERR_UNSUPPORTED) return rr;
+  }
+  if (mode == 1 && g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 2 && g.sw == 2 && g.pt == 0 && g.ph == 1 &&
+      g.pw == 1 && (g.C / vec) <= 128 && (int64_t)g.B * g.H * g.T * g.Hs * g.Ws < (1 << 25) &&
+      (dtype == DCC_BF16 || dtype == DCC_F32)) {
+    RunGeom r = make_run_geom(g, vec, 4);
+    if (set_spans(r, dtype == DCC_BF16 ? 2 : 4, dtype == DCC_BF16 ? 2 : 4)) {
+      const int items = g.B * g.H * g.To * g.Ho * g.Wo + (g.has_cls ? g.B * g.H : 0);
+      const dim3 grid2((items + r.slots - 1) / r.slots);
+      if (dtype == DCC_BF16) hipLaunchKernelGGL((maxpool_s2_fwd_kernel<bf16_t>), grid2, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, argmax, r);
+      else hipLaunchKernelGGL((maxpool_s2_fwd_kernel<float>), grid2, dim3(256), 0, s, (const float*)x, (float*)y, argmax, r);
+      return dcc_check_launch();
+    }
   }
   const int64_t total = (int64_t)g.B * (g.To * g.Ho * g.Wo + g.has_cls) * g.H * (g.C / vec);
   dim3 grid(blocks_for(total, 256, 8192));
