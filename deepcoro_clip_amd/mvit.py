@@ -51,6 +51,28 @@ def block_plan(temporal_size: int, spatial_size: Sequence[int]):
     return plan
 
 
+def forward_macs(plan, patch_tokens: int | None = None) -> dict:
+    """Multiply-accumulates of one clip's forward pass, per piece (torchvision publishes 64.224 GMACs for
+    16 x 224 x 224).  Used by bench.py's roofline accounting and pinned by tests/test_host_cpu.py."""
+    macs = {k: 0 for k in ("conv_proj", "qkv", "pool", "attn", "relpos", "proj", "skip", "mlp")}
+    l0 = patch_tokens if patch_tokens is not None else math.prod(plan[0]["thw"])
+    macs["conv_proj"] = l0 * 96 * 3 * 3 * 7 * 7
+    for p in plan:
+        cin, cout, h = p["in_ch"], p["out_ch"], p["heads"]
+        hd = cout // h
+        nin, nq, nk = math.prod(p["thw"]) + 1, math.prod(p["q_thw"]) + 1, math.prod(p["k_thw"]) + 1
+        macs["qkv"] += nin * cin * 3 * cout
+        macs["pool"] += ((nq - 1) + 2 * (nk - 1)) * cout * 27
+        macs["attn"] += 2 * h * nq * nk * hd
+        macs["relpos"] += h * (nq - 1) * hd * sum(p["k_thw"])
+        macs["proj"] += nq * cout * cout
+        if cin != cout:
+            macs["skip"] += nin * cin * cout
+        macs["mlp"] += 2 * nq * cout * 4 * cout
+    macs["total"] = sum(macs.values())
+    return macs
+
+
 class _Pool(nn.Module):
     """container: torchvision mvit.Pool(Conv3d depthwise, LayerNorm)"""
 

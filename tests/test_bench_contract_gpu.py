@@ -23,11 +23,14 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["higher_is_better"] is True
     assert out["scaling"] == "weak" and out["vs_baseline"] is None and out["dtype"] == "bf16" and out["data"] == "synthetic"
-    assert out["value"] > 0 and abs(out["value"] - 2 / (out["ms_per_step"] * 1e-3)) < 1e-2 * out["value"]
+    # default workload = the headline multi-video config (N = 4 videos per study, attention pooling)
+    assert out["config"]["clips_per_step"] == 8 and "multi-video" in out["config"]["workload"]
+    assert out["value"] > 0 and abs(out["value"] - 8 / (out["ms_per_step"] * 1e-3)) < 1e-2 * out["value"]
     assert "workload" in out["config"] and "model" not in out["config"]
     rf = out["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and "traffic" in rf
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["frac"] == max(rf["mfma"]["frac"], rf["hbm"]["frac"]) and 0 < rf["video_fwd_frac"] < 1
     cb = out["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"] and cb["unit"]
 

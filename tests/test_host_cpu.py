@@ -66,6 +66,24 @@ def test_block_plan_geometry():
     assert block_plan(4, (112, 112))[15]["q_thw"] == (2, 4, 4)
 
 
+def test_forward_macs_known_answers():
+    """SURVEY §8d / BASELINE.md §2 known answers: torchvision publishes 64.224 GMACs for mvit_v2_s at 16 x 224 x 224;
+    the per-piece split and the two size-parameterised totals (4 x 112^2: 6.60 GFLOP, 32 x 224^2: 314.80 GFLOP)."""
+    from deepcoro_clip_amd.mvit import block_plan, forward_macs
+
+    m = forward_macs(block_plan(16, (224, 224)))
+    assert abs(m["total"] / 1e9 - 64.224) < 1e-3, m["total"]
+    gflop = {k: round(2 * v / 1e9, 2) for k, v in m.items()}
+    assert gflop == {"conv_proj": 2.12, "qkv": 26.37, "pool": 1.09, "attn": 28.86, "relpos": 0.59, "proj": 7.40,
+                     "skip": 2.78, "mlp": 59.24, "total": 128.45}, gflop
+    assert round(2 * forward_macs(block_plan(4, (112, 112)))["total"] / 1e9, 2) == 6.60
+    assert round(2 * forward_macs(block_plan(32, (224, 224)))["total"] / 1e9, 2) == 314.80
+    # backbone parameter count with the Identity head (torchvision: 34 537 744 with the 400-way head)
+    from deepcoro_clip_amd.mvit import HipMViT
+    n = sum(p.numel() for p in HipMViT().parameters())
+    assert n == 34_230_144 and n + 768 * 400 + 400 == 34_537_744
+
+
 def test_video_encoder_contract_and_freezing():
     from deepcoro_clip_amd.video_encoder import VideoEncoder
     from oracle.model import VideoEncoderOracle
