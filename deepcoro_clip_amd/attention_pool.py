@@ -25,15 +25,12 @@ class AttentionPool(nn.Module):
         """x: [B, N, D] (compute dtype) -> [B, output_dim]."""
         if mask is not None:
             raise NotImplementedError("key_padding_mask is unused on the contrastive path (models/video_encoder.py:597-602)")
-        if self.training and self.attn_dropout > 0:
-            raise NotImplementedError("attention-weight dropout inside AttentionPool is not implemented on the HIP path; "
-                                      "use attention_pool_dropout=0")
         B, N, D = x.shape
         assert D == self.embed_dim, f"Input dim {D} != expected {self.embed_dim}"
         q = Fn.cast(self.query, x.dtype).expand(B, 1, D)
         a = self.attn
         o = Fn.multihead_attention(q, x, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
-                                   self.num_heads, self_attn=False)
+                                   self.num_heads, self_attn=False, dropout_p=self.attn_dropout, training=self.training)
         o = Fn.layernorm(o, self.norm.weight, self.norm.bias, self.norm.eps)
         if isinstance(self.proj, nn.Linear):
             o = Fn.linear(o, self.proj.weight, self.proj.bias)

@@ -1,6 +1,11 @@
 // Flash-style multi-head attention for gfx950: forward, dQ and dK/dV kernels.
 //
-//   z[q][k] = scale * <Qf[q], Kf[k]> + kbias[k];  P = softmax_k(z);  O = P V (+ Qres residual)
+//   z[q][k] = scale * <Qf[q], Kf[k]> + kbias[k];  P = softmax_k(z);  O = dropout(P) V (+ Qres residual)
+//
+// dropout(P) = P * keep / (1 - p) is nn.MultiheadAttention(dropout=p) / HF BERT attention_probs_dropout_prob: applied to
+// the NORMALISED probabilities, so the softmax denominator l sums the undropped tile and only the tile that feeds the
+// P V product is masked.  keep(b, h, q, k) is a counter hash of (seed, device step counter, element) that the two
+// backward kernels regenerate: dV = dropout(P)^T dO, dz = P * (keep/(1-p) * (dO V^T) - D), D = rowsum(dO * O).
 //
 // Qf/Kf are DQK wide, V/O are DV wide.  MViT's decomposed relative-position bias is folded into
 // the contraction: Qf = [q | tab(q)/scale], Kf = [k | one-hot(k_t,k_h,k_w)], so the bias costs
@@ -27,6 +32,10 @@ struct AttnParams {
   float scale;
   int res_start;
   int qsplit;
+  // attention-probability dropout (0 = off): mask = hash32(seed', (row << 32) | key) >= thr, row = (b*H + h)*Nq + q
+  float drop_p;
+  uint64_t drop_seed;
+  const int64_t* drop_step;   // nullable device counter mixed into the seed (HIP-graph replays draw fresh masks)
 };
 
 namespace {
@@ -38,6 +47,21 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr int ANT = 256;  // threads per block
+
+struct DropCtx {
+  uint64_t seed; uint32_t thr; float inv_keep;
+  __device__ __forceinline__ void init(const AttnParams& p) {
+    seed = p.drop_seed;
+    if (p.drop_step) seed += (uint64_t)(*p.drop_step) * 0x9E3779B97F4A7C15ULL;
+    seed *= 0x100000001b3ULL;
+    thr = (uint32_t)((double)p.drop_p * 4294967296.0);
+    inv_keep = 1.0f / (1.0f - p.drop_p);
+  }
+  // multiplier of P[row][key]: 0 or 1/(1-p)
+  __device__ __forceinline__ float mul(uint32_t row, uint32_t key) const {
+    return hash32(seed + (((uint64_t)row << 32) | key)) >= thr ? inv_keep : 0.0f;
+  }
+};
 constexpr int TK = 64;    // rows staged per LDS tile
 
 template <typename T, int D> struct RowTile {  // [rows][D] tile with padded pitch
@@ -184,7 +208,7 @@ __device__ __forceinline__ void store_tile_T(T* rowptr, int t, int h, const f32x
 
 // ------------------------------------------------------------------------------------------
 // forward: one wave = 32 queries, block = 128 queries; keys/values staged 64 rows at a time.
-template <typename T, int DQK, int DV>
+template <typename T, int DQK, int DV, bool DROP>
 __global__ __launch_bounds__(ANT) void attn_fwd_kernel(AttnParams p) {
   using KT = RowTile<T, DQK>;
   using VT = RowTile<T, DV>;
@@ -212,6 +236,9 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(AttnParams p) {
     for (int e = 0; e < 16; ++e) oacc[t][e] = 0.0f;
   float m = -INFINITY, l = 0.0f;
   const float scale2 = p.scale * LOG2E;
+  DropCtx dc;
+  if constexpr (DROP) dc.init(p);
+  const uint32_t drow = (uint32_t)((b * p.H + hd) * p.Nq + myq);
 
   TileRegs<T, DQK> rk;
   TileRegs<T, DV> rv;
@@ -261,6 +288,10 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(AttnParams p) {
       rs += xhalf(rs);
       l = l * alpha + rs;
       m = mnew;
+      if constexpr (DROP) {  // mask the tile that feeds P V; l keeps the undropped sum (softmax, THEN dropout)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] *= dc.mul(drow, (uint32_t)(kt0 + 32 * sub + acc_row(e, h)));
+      }
 #pragma unroll
       for (int t = 0; t < DV / 32; ++t)
 #pragma unroll
@@ -289,7 +320,7 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(AttnParams p) {
 
 // ------------------------------------------------------------------------------------------
 // dQ: same decomposition as the forward (queries on lanes).
-template <typename T, int DQK, int DV>
+template <typename T, int DQK, int DV, bool DROP>
 __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
   using KT = RowTile<T, DQK>;
   using VT = RowTile<T, DV>;
@@ -342,6 +373,9 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[t][e] = 0.0f;
   const float scale2 = p.scale * LOG2E;
+  DropCtx dc;
+  if constexpr (DROP) dc.init(p);
+  const uint32_t drow = (uint32_t)((b * p.H + hd) * p.Nq + myq);
 
   TileRegs<T, DQK> rk;
   TileRegs<T, DV> rv;
@@ -374,6 +408,10 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
       for (int s = 0; s < DQK / 16; ++s) S = mma16(row_frag<T, DQK>(ldsK, 32 * sub, s, lane), qf[s], S);
 #pragma unroll
       for (int s = 0; s < DV / 16; ++s) dP = mma16(row_frag<T, DV>(ldsV, 32 * sub, s, lane), dof[s], dP);
+      if constexpr (DROP) {  // dP = keep/(1-p) * (dO V^T)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dP[e] *= dc.mul(drow, (uint32_t)(kt0 + 32 * sub + acc_row(e, h)));
+      }
       const bool plain = !p.kbias && (kt0 + 32 * sub + 32 <= p.Nk);  // no key bias, no tail: skip the bias reads
       if (plain) {
 #pragma unroll
@@ -406,7 +444,7 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------
 // dK/dV: keys on lanes (one wave = 32 keys, block = 128 keys), queries staged 64 rows at a time.
 // blockIdx.x = key block * qsplit + query split.
-template <typename T, typename TO, int DQK, int DV>
+template <typename T, typename TO, int DQK, int DV, bool DROP>
 __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
   using QT = RowTile<T, DQK>;
   using OT = RowTile<T, DV>;
@@ -449,6 +487,10 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) dvv[t][e] = 0.0f;
   const float scale2 = p.scale * LOG2E;
+
+  DropCtx dc;
+  if constexpr (DROP) dc.init(p);
+  const uint32_t drow0 = (uint32_t)((b * p.H + hd) * p.Nq);
 
   // query range of this split, in units of TK rows
   const int qtiles = (p.Nq + TK - 1) / TK;
@@ -493,8 +535,14 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
       for (int e = 0; e < 16; ++e) {
         const int qi = 32 * sub + acc_row(e, h);
         const float pr = fast_exp2(S[e] * scale2 + kb2 - ldsL[qi]);
-        S[e] = pr;                        // P
-        dP[e] = pr * (dP[e] - ldsD[qi]);  // dz
+        if constexpr (DROP) {
+          const float mk = dc.mul(drow0 + (uint32_t)(qq0 + qi), (uint32_t)mykey);
+          S[e] = pr * mk;                        // dropout(P): feeds dV
+          dP[e] = pr * (dP[e] * mk - ldsD[qi]);  // dz
+        } else {
+          S[e] = pr;                        // P
+          dP[e] = pr * (dP[e] - ldsD[qi]);  // dz
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -552,29 +600,36 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
-template <typename T, int DQK, int DV>
+template <typename T, int DQK, int DV, bool DROP>
 int launch_attn(int which, const AttnParams& p, int out_f32, hipStream_t st) {
   if (which == 0) {
     dim3 grid((p.Nq + 127) / 128, p.H, p.B);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, DQK, DV>), grid, dim3(ANT), 0, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DQK, DV, DROP>), grid, dim3(ANT), 0, st, p);
   } else if (which == 1) {
     dim3 grid((p.Nq + 127) / 128, p.H, p.B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DQK, DV>), grid, dim3(ANT), 0, st, p);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DQK, DV, DROP>), grid, dim3(ANT), 0, st, p);
   } else {
     dim3 grid(((p.Nk + 127) / 128) * p.qsplit, p.H, p.B);
-    if (out_f32) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, float, DQK, DV>), grid, dim3(ANT), 0, st, p);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, T, DQK, DV>), grid, dim3(ANT), 0, st, p);
+    if (out_f32) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, float, DQK, DV, DROP>), grid, dim3(ANT), 0, st, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, T, DQK, DV, DROP>), grid, dim3(ANT), 0, st, p);
   }
   return dcc_check_launch();
 }
 
 template <typename T>
 int dispatch_dims(int which, const AttnParams& p, int dqk, int dv, int out_f32, hipStream_t st) {
-  if (dqk == 64 && dv == 64) return launch_attn<T, 64, 64>(which, p, out_f32, st);
-  if (dqk == 96 && dv == 96) return launch_attn<T, 96, 96>(which, p, out_f32, st);
-  if (dqk == 128 && dv == 96) return launch_attn<T, 128, 96>(which, p, out_f32, st);
-  if (dqk == 160 && dv == 96) return launch_attn<T, 160, 96>(which, p, out_f32, st);
-  if (dqk == 128 && dv == 128) return launch_attn<T, 128, 128>(which, p, out_f32, st);
+  if (p.drop_p > 0.0f) {
+    // attention-probability dropout exists where nn.MultiheadAttention / HF BERT have it: 64-wide heads (BERT-base,
+    // AttentionPool 512/8) and 128-wide heads (study aggregator 512/4); MViT's pooled attention has none
+    if (dqk == 64 && dv == 64) return launch_attn<T, 64, 64, true>(which, p, out_f32, st);
+    if (dqk == 128 && dv == 128) return launch_attn<T, 128, 128, true>(which, p, out_f32, st);
+    return DCC_ERR_UNSUPPORTED;
+  }
+  if (dqk == 64 && dv == 64) return launch_attn<T, 64, 64, false>(which, p, out_f32, st);
+  if (dqk == 96 && dv == 96) return launch_attn<T, 96, 96, false>(which, p, out_f32, st);
+  if (dqk == 128 && dv == 96) return launch_attn<T, 128, 96, false>(which, p, out_f32, st);
+  if (dqk == 160 && dv == 96) return launch_attn<T, 160, 96, false>(which, p, out_f32, st);
+  if (dqk == 128 && dv == 128) return launch_attn<T, 128, 128, false>(which, p, out_f32, st);
   return DCC_ERR_UNSUPPORTED;
 }
 
@@ -594,8 +649,9 @@ int check_common(const AttnParams& p, int dtype) {
 
 extern "C" int dcc_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, const float* kbias,
                             const void* Qres, int res_start, const int64_t* strides /*12: q,k,v,o x (b,n,h)*/, int B,
-                            int H, int Nq, int Nk, int DQK, int DV, float scale, int dtype, void* stream) {
-  if (!Q || !K || !V || !O || !strides) return DCC_ERR_ARG;
+                            int H, int Nq, int Nk, int DQK, int DV, float scale, float drop_p, uint64_t drop_seed,
+                            const int64_t* drop_step, int dtype, void* stream) {
+  if (!Q || !K || !V || !O || !strides || !(drop_p >= 0.0f && drop_p < 1.0f)) return DCC_ERR_ARG;
   AttnParams p{};
   p.Q = Q; p.K = K; p.V = V; p.O = O; p.LSE = LSE; p.kbias = kbias; p.Qres = Qres; p.res_start = res_start;
   p.sqb = strides[0]; p.sqn = strides[1]; p.sqh = strides[2];
@@ -603,6 +659,7 @@ extern "C" int dcc_attn_fwd(const void* Q, const void* K, const void* V, void* O
   p.svb = strides[6]; p.svn = strides[7]; p.svh = strides[8];
   p.sob = strides[9]; p.son = strides[10]; p.soh = strides[11];
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = 1;
+  p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_step = drop_step;
   int rc = check_common(p, dtype);
   if (rc) return rc;
   if (dtype == DCC_BF16) return dispatch_dims<bf16_t>(0, p, DQK, DV, 0, (hipStream_t)stream);
@@ -615,8 +672,10 @@ extern "C" int dcc_attn_fwd(const void* Q, const void* K, const void* V, void* O
 extern "C" int dcc_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
                             const float* LSE, float* Dv, const float* kbias, const void* Qres, int res_start, void* dQ,
                             void* dK, void* dV, const int64_t* strides /*21: q,k,v,o,dq,dk,dv x (b,n,h)*/, int B, int H,
-                            int Nq, int Nk, int DQK, int DV, float scale, int qsplit, int dtype, void* stream) {
+                            int Nq, int Nk, int DQK, int DV, float scale, int qsplit, float drop_p, uint64_t drop_seed,
+                            const int64_t* drop_step, int dtype, void* stream) {
   if (!Q || !K || !V || !O || !dO || !LSE || !Dv || !dQ || !dK || !dV || !strides) return DCC_ERR_ARG;
+  if (!(drop_p >= 0.0f && drop_p < 1.0f)) return DCC_ERR_ARG;
   if (qsplit < 1) return DCC_ERR_ARG;
   AttnParams p{};
   p.Q = Q; p.K = K; p.V = V; p.O = const_cast<void*>(O); p.dO = dO; p.LSE = const_cast<float*>(LSE); p.Dv = Dv;
@@ -629,6 +688,7 @@ extern "C" int dcc_attn_bwd(const void* Q, const void* K, const void* V, const v
   p.sdkb = strides[15]; p.sdkn = strides[16]; p.sdkh = strides[17];
   p.sdvb = strides[18]; p.sdvn = strides[19]; p.sdvh = strides[20];
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = qsplit;
+  p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_step = drop_step;
   int rc = check_common(p, dtype);
   if (rc) return rc;
   for (int i = 12; i < 21; ++i)

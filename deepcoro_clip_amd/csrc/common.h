@@ -112,6 +112,16 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * 0.39894228040143267794f * e;
 }
 
+// Counter-based keep masks (dropout): splitmix64 finaliser of (seed, element index); a mask is regenerated from the
+// same (seed, index) wherever it is needed again (backward) instead of being stored.
+__device__ __forceinline__ uint32_t hash32(uint64_t k) {
+  k += 0x9e3779b97f4a7c15ULL;
+  k = (k ^ (k >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  k = (k ^ (k >> 27)) * 0x94d049bb133111ebULL;
+  k ^= k >> 31;
+  return (uint32_t)(k >> 32);
+}
+
 static inline int dcc_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DCC_OK : DCC_ERR_LAUNCH;

@@ -315,13 +315,6 @@ __global__ void nan_to_num_kernel(T* __restrict__ x, int64_t n, float nanv, floa
   if (count && local) atomicAdd(count, local);
 }
 
-__device__ __forceinline__ uint32_t hash32(uint64_t k) {  // splitmix64 finaliser
-  k += 0x9e3779b97f4a7c15ULL;
-  k = (k ^ (k >> 30)) * 0xbf58476d1ce4e5b9ULL;
-  k = (k ^ (k >> 27)) * 0x94d049bb133111ebULL;
-  k ^= k >> 31;
-  return (uint32_t)(k >> 32);
-}
 // y = x * keep / (1-p); keep regenerated from (seed, index) so no mask is stored.  `step` (nullable, device): a counter
 // mixed into the seed, so that a launch replayed from a HIP graph draws a new mask whenever the counter was advanced.
 template <typename T>

@@ -8,7 +8,10 @@ for the MI355X node rather than translating torch's reducer:
   * buckets are large (default 64 MiB): xGMI is point-to-point (7 links x ~153 GB/s), ring/direct collectives are
     per-link bound, so few large messages beat DDP's 25 MiB NVSwitch-era default;
   * a bucket's all-reduce (AVG) is launched from a post-accumulate-grad hook as soon as its last gradient is
-    written — RCCL runs it on its own stream, overlapped with the rest of backward; `finish()` joins them.
+    written — RCCL runs it on its own stream, overlapped with the rest of backward; `finish()` joins them;
+  * gradient accumulation has torch DDP's `no_sync` semantics: `begin_backward(sync=False)` micro-steps only
+    accumulate into the arena, the buckets are reduced once, from the hooks of the window's LAST backward
+    (`begin_backward(sync=True)`, the default), so no collective ever overlaps a later in-place accumulate.
 The same code path runs on gloo/CPU for the world_size-2 tests (SUM + divide, since gloo has no AVG).
 """
 from __future__ import annotations
@@ -37,6 +40,10 @@ class HipDDP(torch.nn.Module):
         self._pending: list[int] = []
         self._bucket_of: dict[int, int] = {}
         self._hooks_installed = False
+        self._sync = True  # reduce from this backward's hooks (False: accumulate-only micro-step of a window)
+        # parameters whose gradient nobody zeroes (outside every optimizer group): their arena slot survives
+        # attach_grads() and stays attached, so the history keeps accumulating as it does under torch DDP
+        self.persistent_grad_ids: set[int] = set()
         if self.world > 1:
             self._broadcast_parameters()
         self._build_arena()
@@ -77,22 +84,37 @@ class HipDDP(torch.nn.Module):
         post-accumulate hook.  Either way `param.grad` is a view into the flat arena when backward returns."""
         if self._arena is None:
             return
+        keep = [(p, self._views[id(p)].clone()) for p in self._order
+                if id(p) in self.persistent_grad_ids and p.grad is not None]
         self._arena.zero_()
         for p in self._order:
             p.grad = None
-            if p.requires_grad:
+            if p.requires_grad and id(p) not in self.persistent_grad_ids:
                 _grad_slots.register(p, self._views[id(p)])
             else:
                 _grad_slots.unregister(p)
-        self._pending = [0] * len(self._buckets)
-        for p in self._order:
-            if p.requires_grad:
-                self._pending[self._bucket_of[id(p)]] += 1
+        for p, hist in keep:  # history back into its slot, gradient stays attached: autograd accumulates in place
+            self._views[id(p)].copy_(hist)
+            p.grad = self._views[id(p)]
         self._handles = []
         if not self._hooks_installed:
             for p in self._order:
                 p.register_post_accumulate_grad_hook(self._make_hook(p))
             self._hooks_installed = True
+        self.begin_backward(sync=True)
+
+    def begin_backward(self, sync: bool = True):
+        """Arm the wrapper for ONE backward pass.  sync=False: a non-final micro-step of a gradient-accumulation window
+        (hooks only move / accumulate gradients into the arena); sync=True: the window's last backward — each bucket's
+        all-reduce starts when the last of its gradients has been written.  `attach_grads()` arms with sync=True, so
+        callers without accumulation never need this."""
+        if self._handles:
+            raise RuntimeError("begin_backward() while bucket all-reduces of the previous backward are in flight: call finish()")
+        self._sync = bool(sync)
+        self._pending = [0] * len(self._buckets)
+        for p in self._order:
+            if p.requires_grad:
+                self._pending[self._bucket_of[id(p)]] += 1
 
     def _make_hook(self, p):
         def hook(param):
@@ -101,7 +123,7 @@ class HipDDP(torch.nn.Module):
             if g is not None and g.data_ptr() != v.data_ptr():  # produced elsewhere: move it into the arena
                 v.copy_(g)
                 param.grad = v
-            if self.world <= 1:
+            if self.world <= 1 or not self._sync:
                 return
             b = self._bucket_of[id(p)]
             if b >= len(self._pending):
@@ -129,6 +151,9 @@ class HipDDP(torch.nn.Module):
                 p.grad = self._views[id(p)]
         if self.world <= 1:
             return
+        if not self._sync:
+            raise RuntimeError("finish() after an accumulate-only backward: the window's last backward must be armed with "
+                               "begin_backward(sync=True)")
         for b, n in enumerate(self._pending):
             if n > 0:
                 self._pending[b] = 0

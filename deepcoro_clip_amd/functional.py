@@ -338,25 +338,34 @@ def layernorm_skip(x, gamma, beta, eps: float):
 
 # ---------------------------------------------------------------------------------- attention
 class AttentionFn(torch.autograd.Function):
-    """softmax(scale q k^T + kbias) v on [B, N, H, D] views (BERT self-attention, nn.MultiheadAttention core)."""
+    """dropout(softmax(scale q k^T + kbias)) v on [B, N, H, D] views (BERT self-attention, nn.MultiheadAttention core)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, kbias, scale):
-        o, lse = K.attn_fwd(q, k, v, scale=scale, kbias=kbias)
+    def forward(ctx, q, k, v, kbias, scale, drop):
+        p, seed, step = drop
+        o, lse = K.attn_fwd(q, k, v, scale=scale, kbias=kbias, drop_p=p, drop_seed=seed, drop_step=step)
         ctx.save_for_backward(q, k, v, o, lse, kbias)
-        ctx.scale = scale
+        ctx.scale, ctx.drop = scale, drop
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse, kbias = ctx.saved_tensors
         do = _c(do)
-        dq, dk, dv = K.attn_bwd(q, k, v, o, do, lse, scale=ctx.scale, kbias=kbias)
-        return dq, _as_dtype(dk, q.dtype), _as_dtype(dv, q.dtype), None, None
+        p, seed, step = ctx.drop
+        dq, dk, dv = K.attn_bwd(q, k, v, o, do, lse, scale=ctx.scale, kbias=kbias, drop_p=p, drop_seed=seed, drop_step=step)
+        return dq, _as_dtype(dk, q.dtype), _as_dtype(dv, q.dtype), None, None, None
 
 
-def attention(q, k, v, scale: float, kbias=None):
-    return AttentionFn.apply(q, k, v, kbias, scale)
+def attention(q, k, v, scale: float, kbias=None, dropout_p: float = 0.0, training: bool = False):
+    """`dropout_p`: attention-probability dropout (nn.MultiheadAttention(dropout=), HF attention_probs_dropout_prob),
+    active in training mode only; the keep mask is drawn inside the flash kernels from the same seeding scheme as
+    `dropout()` (host call-site seed + device step counter) and regenerated in backward."""
+    drop = (0.0, 0, None)
+    if training and dropout_p > 0.0:
+        seed, step = _dropout_seed(q.device)
+        drop = (float(dropout_p), seed, step)
+    return AttentionFn.apply(q, k, v, kbias, scale, drop)
 
 
 # --------------------------------------------------------------------- MViT pooled attention core
@@ -759,19 +768,23 @@ class DropoutFn(torch.autograd.Function):
         return K.dropout(_c(d), ctx.p, ctx.seed, ctx.step), None, None, None
 
 
+def _dropout_seed(device):
+    """(host seed, device step counter or None) of the next mask-drawing call site (see `begin_step`)."""
+    global _DROPOUT_CALLS
+    step = _STEP["counter"]
+    if step is not None and step.device == device:
+        _STEP["calls"] += 1
+        return (torch.initial_seed() * 1000003 + _STEP["calls"]) & (2**63 - 1), step
+    _DROPOUT_CALLS += 1
+    return (torch.initial_seed() * 1000003 + _DROPOUT_CALLS) & (2**63 - 1), None
+
+
 def dropout(x, p: float, training: bool):
     """nn.Dropout: identity in eval / p == 0; counter-hash keep mask otherwise (mask regenerated in backward)."""
-    global _DROPOUT_CALLS
     if not training or p <= 0.0:
         return x
-    step = _STEP["counter"]
-    if step is not None and step.device == x.device:
-        _STEP["calls"] += 1
-        seed = (torch.initial_seed() * 1000003 + _STEP["calls"]) & (2**63 - 1)
-        return DropoutFn.apply(x, float(p), seed, step)
-    _DROPOUT_CALLS += 1
-    seed = (torch.initial_seed() * 1000003 + _DROPOUT_CALLS) & (2**63 - 1)
-    return DropoutFn.apply(x, float(p), seed, None)
+    seed, step = _dropout_seed(x.device)
+    return DropoutFn.apply(x, float(p), seed, step)
 
 
 class EmbedFn(torch.autograd.Function):
@@ -802,8 +815,10 @@ def embed(ids, word, pos, typ, dtype):
 
 
 # ------------------------------------------------------------------- nn.MultiheadAttention core
-def multihead_attention(query, key_value, in_w, in_b, out_w, out_b, num_heads: int, self_attn: bool):
-    """batch_first nn.MultiheadAttention forward (no masks, no attention dropout) built from our GEMM + attention.
+def multihead_attention(query, key_value, in_w, in_b, out_w, out_b, num_heads: int, self_attn: bool,
+                        dropout_p: float = 0.0, training: bool = False):
+    """batch_first nn.MultiheadAttention forward (no masks) built from our GEMM + attention; `dropout_p` is the module's
+    attention-weight dropout (applied to the softmax output in training mode, inside the flash kernels).
 
     query: [B, Lq, E]; key_value: [B, Lk, E] (key == value).  Weight slices are views of the packed in_proj
     parameters, so gradients flow back to `in_proj_weight` / `in_proj_bias` through autograd's slicing.
@@ -818,5 +833,5 @@ def multihead_attention(query, key_value, in_w, in_b, out_w, out_b, num_heads: i
         q = linear(query, in_w[:E], in_b[:E]).view(B, Lq, num_heads, hd)
         kv = linear(key_value, in_w[E:], in_b[E:]).view(B, Lk, 2, num_heads, hd)
         k, v = kv[:, :, 0], kv[:, :, 1]
-    ctx = attention(q, k, v, 1.0 / math.sqrt(hd))
+    ctx = attention(q, k, v, 1.0 / math.sqrt(hd), dropout_p=dropout_p, training=training)
     return linear(ctx.reshape(B, Lq, E), out_w, out_b)

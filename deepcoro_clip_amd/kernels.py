@@ -189,9 +189,11 @@ def _strides3(t: torch.Tensor) -> list[int]:
 
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: float, kbias: torch.Tensor | None = None,
-             residual: bool = False, res_start: int = 0):
-    """O = softmax(scale * q k^T + kbias) v (+ q[..., :DV] for rows >= res_start). Returns (O [B,Nq,H,DV], LSE [B,H,Nq])."""
-    L.require_cuda(q, k, v, kbias)
+             residual: bool = False, res_start: int = 0, drop_p: float = 0.0, drop_seed: int = 0,
+             drop_step: torch.Tensor | None = None):
+    """O = dropout(softmax(scale * q k^T + kbias)) v (+ q[..., :DV] for rows >= res_start). Returns (O [B,Nq,H,DV],
+    LSE [B,H,Nq]).  drop_p: attention-probability dropout (mask = hash of (drop_seed, *drop_step, element))."""
+    L.require_cuda(q, k, v, kbias, drop_step)
     B, Nq, H, DQK = q.shape
     Nk, DV = k.shape[1], v.shape[3]
     assert k.shape == (B, Nk, H, DQK) and v.shape == (B, Nk, H, DV) and q.dtype == k.dtype == v.dtype
@@ -202,13 +204,13 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: float,
     st = _i64(_strides3(q) + _strides3(k) + _strides3(v) + _strides3(o))
     with _timed("attn_fwd", 2.0 * B * H * Nq * Nk * (DQK + DV), lambda: f"B{B} H{H} Nq{Nq} Nk{Nk} D{DQK}/{DV}"):
         L.call("dcc_attn_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(kbias),
-               L.ptr(q) if residual else None, int(res_start), st, B, H, Nq, Nk, DQK, DV, float(scale), L.dt(q),
-               L.stream())
+               L.ptr(q) if residual else None, int(res_start), st, B, H, Nq, Nk, DQK, DV, float(scale), float(drop_p),
+               ctypes.c_uint64(drop_seed & (2**64 - 1)), L.ptr(drop_step), L.dt(q), L.stream())
     return o, lse
 
 
 def attn_bwd(q, k, v, o, do, lse, *, scale: float, kbias=None, residual: bool = False, res_start: int = 0,
-             qsplit: int | None = None):
+             qsplit: int | None = None, drop_p: float = 0.0, drop_seed: int = 0, drop_step: torch.Tensor | None = None):
     """Gradients of attn_fwd w.r.t. q (including the residual shortcut's dO when `residual`), k, v.
 
     dk/dv come back in fp32 when the query range is split (atomic accumulation)."""
@@ -231,7 +233,8 @@ def attn_bwd(q, k, v, o, do, lse, *, scale: float, kbias=None, residual: bool = 
     with _timed("attn_bwd", 2.0 * B * H * Nq * Nk * (3 * DQK + 4 * DV), lambda: f"B{B} H{H} Nq{Nq} Nk{Nk} D{DQK}/{DV} qs{qsplit}"):
         L.call("dcc_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(dvec),
                L.ptr(kbias), L.ptr(q) if residual else None, int(res_start), L.ptr(dq), L.ptr(dk), L.ptr(dv), st, B, H,
-               Nq, Nk, DQK, DV, float(scale), int(qsplit), L.dt(q), L.stream())
+               Nq, Nk, DQK, DV, float(scale), int(qsplit), float(drop_p), ctypes.c_uint64(drop_seed & (2**64 - 1)),
+               L.ptr(drop_step), L.dt(q), L.stream())
     return dq, dk, dv
 
 

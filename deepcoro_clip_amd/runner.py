@@ -146,7 +146,29 @@ class VideoContrastiveLearningRunner:
             # accumulation-produced gradients of this step come out of one pre-zeroed arena (one memset per step)
             dev = self.log_temp.device if self.log_temp is not None else torch.device("cuda")
             hint = sum(p.numel() for g in self.optimizer.param_groups for p in g["params"]) + (1 << 20)
+            self._rehome_orphan_grads()
             Fn.ARENA.begin(dev, hint)
+
+    def _rehome_orphan_grads(self):
+        """Gradients nobody zeroes (parameters outside every optimizer group: the reference's video `proj`, a loss module's
+        own bias — SURVEY §9.11) keep accumulating across steps.  When such a `.grad` is a slice of the per-step zero arena
+        it must leave the arena before `begin()` re-zeroes and re-issues that memory: clone it out once; from then on
+        autograd accumulates into the private clone."""
+        buf = Fn.ARENA.buf
+        if buf is None:
+            return
+        if getattr(self, "_orphans", None) is None:
+            in_opt = {id(p) for g in self.optimizer.param_groups for p in g["params"]}
+            mods = [self.video_encoder, self.text_encoder]
+            lt = getattr(self.loss_fn, "loss_type", self.loss_fn)
+            if isinstance(lt, torch.nn.Module):
+                mods.append(lt)
+            self._orphans = [p for m in mods if m is not None for p in m.parameters() if id(p) not in in_opt]
+        lo, hi = buf.data_ptr(), buf.data_ptr() + buf.numel() * 4
+        for p in self._orphans:
+            g = p.grad
+            if g is not None and lo <= g.data_ptr() < hi:
+                p.grad = g.clone()
 
     def _all_encoder_params(self):
         return list(itertools.chain(self.video_encoder.parameters(), self.text_encoder.parameters()))
@@ -264,9 +286,9 @@ class VideoContrastiveLearningRunner:
         if scal is not None:
             pack[2:9] = scal[:7] if scal.numel() >= 7 else 0
         capturing = torch.cuda.is_current_stream_capturing()
-        if capturing:  # captured step: the copy node writes this fixed buffer at every replay (see StepGraph)
+        if capturing:  # captured step: the copy node writes this fixed buffer at every replay (_graph_train_step)
             if getattr(self, "_graph_host", None) is None:
-                raise RuntimeError("graph capture needs runner._graph_host (use StepGraph)")
+                raise RuntimeError("graph capture needs runner._graph_host (set by _graph_train_step)")
             host = self._graph_host
         else:
             host = torch.empty(10, dtype=torch.float32, pin_memory=True)
@@ -330,6 +352,9 @@ class VideoContrastiveLearningRunner:
             self._accum_grad = torch.full((), 1.0 / accum, device=clip_loss.device, dtype=clip_loss.dtype)
         # weight-gradient GEMMs off the critical chain (functional.wgrad): safe when every gradient buffer is adopted as is
         Fn.WGRAD_SIDE = self._wgrad_side and accum == 1 and self.world_size == 1 and not self._ddp_wrappers()
+        if accum > 1:  # torch DDP's no_sync(): only the window's last backward reduces the gradient buckets
+            for w in self._ddp_wrappers():
+                w.begin_backward(sync=(self.step + 1) % accum == 0)
         try:
             # backward on the calling thread: handing ~670 nodes to the engine's device thread one by one costs the host
             # ~13 % of a step's launch time (31.0 -> 26.9 ms on launch-bound 112^2 inputs), and the host is the limit on
@@ -356,6 +381,8 @@ class VideoContrastiveLearningRunner:
                 in_opt = {id(p) for g in self.optimizer.param_groups for p in g["params"]}
                 orphans = [p for p in self._clipper.params if id(p) not in in_opt]
                 self._orphan_clipper = GradClipper(orphans) if orphans else None
+                for w in self._ddp_wrappers():
+                    w.persistent_grad_ids = {id(p) for p in orphans}
             fuse = isinstance(self.optimizer, HipAdamW)  # the update kernel applies the coefficient on the fly
             self._clipper.clip_(float(max_norm), scale=not fuse)
             fused_clip = self._clipper.coef if fuse else None
@@ -507,16 +534,20 @@ class VideoContrastiveLearningRunner:
         dist.all_gather_into_tensor(out, padded)
         return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world_size)], dim=0)
 
-    def _maybe_reduce_metrics(self, metrics: dict) -> dict:
-        """One packed all-reduce instead of one per key (reference :1056-1069)."""
+    def _maybe_reduce_metrics(self, metrics: dict, rank0_only=()) -> dict:
+        """One packed all-reduce instead of one per key (reference :1056-1069).  Every rank must pass the same keys.
+        `rank0_only`: keys computed on the reference rank alone (the retrieval metrics; the other ranks hold 0.0
+        placeholders like the reference's :1023-1033): they are SUMMED, so every rank ends up with rank 0's value — the
+        reference averages them with the placeholders and so reports value / world_size, and its placeholder keys
+        ("MRR", "NDCG@k") do not even match rank 0's ("MRR_V2T", "NDCG@k_V2T"); neither defect is reproduced."""
         if self.world_size < 2 or not (dist.is_available() and dist.is_initialized()):
             return metrics
         keys = sorted(k for k, v in metrics.items() if isinstance(v, (int, float)))
         t = torch.tensor([float(metrics[k]) for k in keys], device=self.device, dtype=torch.float32)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        t = (t / self.world_size).tolist()
+        vals = t.tolist()
         out = dict(metrics)
-        out.update({k: v for k, v in zip(keys, t)})
+        out.update({k: (v if k in rank0_only else v / self.world_size) for k, v in zip(keys, vals)})
         return out
 
     def _run_epoch(self, mode: str, epoch: int) -> dict:
@@ -549,21 +580,34 @@ class VideoContrastiveLearningRunner:
                 plist = list(paths) if paths else []
                 all_paths.extend(plist + [""] * (rows - len(plist)))
         out = {f"{mode}/{k}": v / max(count, 1) for k, v in sums.items()}
-        if not training and all_v:
-            v = self._gather_tensor_along_batch(torch.cat(all_v, 0), self.world_size)
+        retrieval_keys: List[str] = []
+        if not training and (all_v or self.world_size > 1):
+            # every collective below runs on EVERY rank, before the rank-0-only metric computation (a gather inside the
+            # is_ref_device branch deadlocks; a packed all-reduce over different key sets corrupts or hangs)
+            dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
+            v_local = torch.cat(all_v, 0) if all_v else torch.empty((0, 512), device=dev)
+            t_local = torch.cat(all_t, 0) if all_t else torch.empty((0, 512), device=dev)
+            v = self._gather_tensor_along_batch(v_local, self.world_size)
+            t = self._gather_tensor_along_batch(t_local, self.world_size) if t_local.dim() == 2 else t_local
             texts = self._gather_objects(all_texts)
             paths_g = self._gather_objects(all_paths)
             tok = getattr(self.text_encoder.module if hasattr(self.text_encoder, "module") else self.text_encoder,
                           "tokenizer", None)
-            if _cfg(self.config, "is_ref_device", True):
-                if tok is not None and len(texts) == v.shape[0] and any(t for t in texts):
-                    out.update({f"{mode}/{k}": x for k, x in self._unique_text_retrieval(v, texts, paths_g, tok, epoch).items()})
-                else:  # no report texts / no tokenizer: the in-batch pairs are the ground truth (diagonal)
-                    t = self._gather_tensor_along_batch(torch.cat(all_t, 0), self.world_size)
-                    if t.numel() and t.shape[0] == v.shape[0]:
-                        out.update({f"{mode}/{k}": x for k, x in
-                                    self._retrieval_metrics(compute_similarity_matrix(v, t), torch.arange(v.shape[0])).items()})
-        return self._maybe_reduce_metrics(out)
+            retrieval_keys = self._retrieval_metric_keys()
+            ret = {k: 0.0 for k in retrieval_keys}   # non-reference ranks: placeholders under the same keys (reference :1023-1033)
+            if _cfg(self.config, "is_ref_device", True) and v.shape[0]:
+                if tok is not None and len(texts) == v.shape[0] and any(x for x in texts):
+                    ret.update(self._unique_text_retrieval(v, texts, paths_g, tok, epoch))
+                elif t.numel() and t.shape[0] == v.shape[0]:
+                    # no report texts / no tokenizer: the in-batch pairs are the ground truth (diagonal)
+                    ret.update(self._retrieval_metrics(compute_similarity_matrix(v, t), torch.arange(v.shape[0])))
+            out.update({f"{mode}/{k}": float(x) for k, x in ret.items() if k in retrieval_keys})
+        return self._maybe_reduce_metrics(out, rank0_only={f"{mode}/{k}" for k in retrieval_keys})
+
+    def _retrieval_metric_keys(self) -> List[str]:
+        """The retrieval keys every rank reports at the end of a validation epoch (same order on all ranks)."""
+        return [f"Recall@{k}" for k in self.config.recall_k] + ["MRR_V2T"] + [f"NDCG@{k}_V2T" for k in self.config.ndcg_k] + \
+               ["MAP", "MedianRank_V2T"]
 
     # ------------------------------------------------------------------------- epoch-end retrieval (val)
     @staticmethod
@@ -665,15 +709,29 @@ class VideoContrastiveLearningRunner:
                 self.lr_scheduler.step()
             if self.wandb_wrapper is not None and getattr(self.wandb_wrapper, "is_initialized", lambda: False)():
                 self.wandb_wrapper.log({**train_metrics, **val_metrics, "epoch": epoch})
-            if _cfg(self.config, "is_ref_device", True) and self.output_dir:
-                val_loss = val_metrics.get("val/loss", float("inf"))
-                is_best = val_loss < self.best_val_loss
-                if is_best:
-                    self.best_val_loss, self.best_epoch = val_loss, epoch
-                self._save_checkpoint(epoch, {**train_metrics, **val_metrics}, is_best)
+            # best / highest-alignment bookkeeping on every rank (reference :385-430), files on the reference rank only
+            save = _cfg(self.config, "is_ref_device", True) and self.output_dir
+            all_metrics = {**train_metrics, **val_metrics}
+            val_loss = val_metrics.get("val/loss", float("inf"))
+            if val_loss < self.best_val_loss:
+                self.best_val_loss, self.best_epoch = val_loss, epoch
+                if save:
+                    self._save_checkpoint(epoch, all_metrics, is_best=True)
+            align = val_metrics.get("val/alignment_score", float("-inf"))
+            if align > self.highest_alignment_score:
+                self.highest_alignment_score, self.highest_alignment_epoch = align, epoch
+                if save:
+                    self._save_checkpoint(epoch, all_metrics, is_best=False, is_highest_alignment=True)
+            if save:
+                self._save_checkpoint(epoch, all_metrics, is_best=False)
+            DistributedUtils.sync_process_group(self.world_size, self.device)
+            patience = _cfg(self.config, "early_stop_patience", 0)
+            if patience and patience > 0 and self.best_epoch >= 0 and epoch - self.best_epoch >= patience:
+                break
 
-    def _save_checkpoint(self, epoch: int, metrics: dict, is_best: bool = False) -> None:
-        """Reference checkpoint layout (:1071-1115): encoders unwrapped from DDP, optimizer, scheduler, metrics."""
+    def _save_checkpoint(self, epoch: int, metrics: dict, is_best: bool = False, is_highest_alignment: bool = False) -> None:
+        """Reference checkpoint layout and file names (:1071-1115): encoders unwrapped from DDP, optimizer, scheduler,
+        scaler, epoch, the epoch metrics, best_val_loss / best_epoch / highest_alignment_score / highest_alignment_epoch."""
         ckpt_dir = os.path.join(self.output_dir, "checkpoints")
         os.makedirs(ckpt_dir, exist_ok=True)
         unwrap = lambda m: m.module if hasattr(m, "module") else m  # noqa: E731
@@ -682,13 +740,20 @@ class VideoContrastiveLearningRunner:
             "text_encoder": unwrap(self.text_encoder).state_dict(),
             "optimizer": self.optimizer.state_dict() if self.optimizer else None,
             "scheduler": self.lr_scheduler.state_dict() if self.lr_scheduler else None,
+            "epoch": epoch,
             "scaler": self.scaler.state_dict() if self.scaler else None,
-            "epoch": epoch, **metrics, "best_val_loss": self.best_val_loss, "best_epoch": self.best_epoch,
-            "train/temperature": float(self.log_temp.detach().exp().item()) if self.log_temp is not None else None,
+            **metrics,
+            "best_val_loss": self.best_val_loss, "best_epoch": self.best_epoch,
+            "highest_alignment_score": self.highest_alignment_score,
+            "highest_alignment_epoch": self.highest_alignment_epoch,
         }
-        torch.save(state, os.path.join(ckpt_dir, "checkpoint.pt"))
         if is_best:
-            torch.save(state, os.path.join(ckpt_dir, f"best_model_epoch_{epoch}.pt"))
+            name = f"best_model_epoch_{epoch}.pt"
+        elif is_highest_alignment:
+            name = f"highest_alignment_epoch_{epoch}.pt"
+        else:
+            name = "checkpoint.pt"
+        torch.save(state, os.path.join(ckpt_dir, name))
 
     def validate(self) -> None:
         raise NotImplementedError("Validation is not implemented for this runner")

@@ -120,15 +120,13 @@ class HipBertModel(nn.Module):
         if attention_mask is not None:
             m = attention_mask.to(torch.float32)
             kbias = ((1.0 - m) * -1e30).contiguous()
-        if self.training and c.attention_probs_dropout_prob > 0:
-            raise NotImplementedError("attention-probability dropout is not implemented in the flash kernel; build the "
-                                      "text trunk with attention_probs_dropout_prob=0")
+        padrop = c.attention_probs_dropout_prob  # HF BertSelfAttention: dropout on the softmax output (training only)
         for l in self.encoder.layer:
             s = l.attention.self
             q = Fn.linear(x, s.query.weight, s.query.bias).view(B, S, H, hd)
             k = Fn.linear(x, s.key.weight, s.key.bias).view(B, S, H, hd)
             v = Fn.linear(x, s.value.weight, s.value.bias).view(B, S, H, hd)
-            ctx = Fn.attention(q, k, v, 1.0 / math.sqrt(hd), kbias).view(B * S, c.hidden_size)
+            ctx = Fn.attention(q, k, v, 1.0 / math.sqrt(hd), kbias, dropout_p=padrop, training=self.training).view(B * S, c.hidden_size)
             o = l.attention.output
             if self.training and pdrop > 0:
                 h = Fn.add(Fn.dropout(Fn.linear(ctx, o.dense.weight, o.dense.bias), pdrop, True), x)

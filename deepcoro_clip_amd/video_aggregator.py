@@ -29,7 +29,7 @@ class TransformerBlock(nn.Module):
         a = self.attn
         h = Fn.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         att = Fn.multihead_attention(h, h, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
-                                     self.num_heads, self_attn=True)
+                                     self.num_heads, self_attn=True, dropout_p=self.p, training=self.training)
         x = Fn.add(x, Fn.dropout(att, self.p, self.training))
         h = Fn.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         if self.training and self.p > 0:

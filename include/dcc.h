@@ -65,17 +65,23 @@ int dcc_gemm(const void* A, const void* B, void* C, const float* bias, const voi
  * Replaces q@k^T*scale, _add_rel_pos, softmax, attn@v and the residual-pool add of torchvision's
  * MultiscaleAttention / the RoPE-patched forward (models/video_encoder.py:348-378), BERT SDPA
  * (models/text_encoder.py:131) and nn.MultiheadAttention's core (models/attention_pool.py:86-91,
- * models/video_aggregator.py:40-45).  (DQK,DV) in {(64,64),(96,96),(128,96),(160,96),(128,128)}. */
+ * models/video_aggregator.py:40-45).  (DQK,DV) in {(64,64),(96,96),(128,96),(160,96),(128,128)}.
+ * drop_p > 0: attention-probability dropout, O = (P * keep / (1 - drop_p)) V with keep a counter hash of
+ * (drop_seed, *drop_step (nullable device counter), b, h, q, k) — nn.MultiheadAttention(dropout=) in
+ * models/attention_pool.py:45-50 and models/video_aggregator.py:16-21, HF BERT attention_probs_dropout_prob
+ * (models/text_encoder.py:52); head shapes (64,64) and (128,128) only.  The backward regenerates the mask from the
+ * same three values. */
 int dcc_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, const float* kbias,
                  const void* Qres, int res_start, const int64_t* strides, int B, int H, int Nq, int Nk, int DQK,
-                 int DV, float scale, int dtype, void* stream);
+                 int DV, float scale, float drop_p, uint64_t drop_seed, const int64_t* drop_step, int dtype,
+                 void* stream);
 /* strides = 21 entries: q,k,v,o,dq,dk,dv x (b,n,h).  Dv: workspace [B,H,Nq] fp32.
  * dK/dV element type: input dtype when qsplit == 1, else fp32 pre-zeroed (atomic accumulation).
  * With Qres != NULL the residual shortcut's gradient (dO for q >= res_start) is added into dQ[:, 0:DV]. */
 int dcc_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                  float* Dv, const float* kbias, const void* Qres, int res_start, void* dQ, void* dK, void* dV,
                  const int64_t* strides, int B, int H, int Nq, int Nk, int DQK, int DV, float scale, int qsplit,
-                 int dtype, void* stream);
+                 float drop_p, uint64_t drop_seed, const int64_t* drop_step, int dtype, void* stream);
 
 /* ---- relative-position bias as contraction (csrc/relpos.hip) -------------------------------
  * torchvision mvit._add_rel_pos (call site models/video_encoder.py:354-364).  The inner products q . R are one

@@ -137,3 +137,131 @@ def test_gather_is_identity_without_process_group():
 
     x = torch.randn(4, 8, requires_grad=True)
     assert gather_all(x) is x
+
+
+def _accum_worker(rank, world, port, q):
+    """Gradient accumulation under HipDDP = torch DDP's no_sync(): accumulate-only micro-steps, ONE reduction from the
+    hooks of the window's last backward; result = mean over ranks of the summed micro-batch gradients."""
+    try:
+        _init(rank, world, port)
+        from deepcoro_clip_amd.ddp import HipDDP
+
+        m = _model(seed=0)
+        w = HipDDP(m, bucket_mb=0.004)  # several buckets
+        ref = _model(seed=0)
+        accum = 3
+
+        def micro(r, i):
+            g = torch.Generator().manual_seed(1000 + 10 * r + i)
+            return torch.randn(4, 16, generator=g), torch.randn(4, 8, generator=g)
+
+        for window in range(2):
+            w.attach_grads()
+            for i in range(accum):
+                w.begin_backward(sync=(i == accum - 1))
+                x, y = micro(rank, i + accum * window)
+                (((w(x) - y) ** 2).mean() / accum).backward()
+                if i < accum - 1:
+                    assert not w._handles, "a non-final micro-step must not launch collectives"
+            w.finish()
+            exp = [torch.zeros_like(p) for p in ref.parameters()]
+            for r in range(world):
+                ref.zero_grad()
+                for i in range(accum):
+                    xr, yr = micro(r, i + accum * window)
+                    (((ref(xr) - yr) ** 2).mean() / accum).backward()
+                for e, p in zip(exp, ref.parameters()):
+                    e += p.grad / world
+            for p, e in zip(m.parameters(), exp):
+                assert torch.allclose(p.grad, e, atol=1e-6), (window, (p.grad - e).abs().max())
+        # ranks agree bit for bit (same reduced arena everywhere)
+        flat = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        other = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        assert torch.equal(other[0], other[1])
+        # a parameter outside every optimizer group keeps its history across attach_grads() (SURVEY §9.11)
+        keep = list(m.parameters())[-1]
+        w.persistent_grad_ids = {id(keep)}
+        before = keep.grad.clone()
+        w.attach_grads()
+        x, y = micro(rank, 99)
+        ((w(x) - y) ** 2).mean().backward()
+        w.finish()
+        ref.zero_grad()
+        new = torch.zeros_like(before)
+        for r in range(world):
+            xr, yr = micro(r, 99)
+            ref.zero_grad()
+            ((ref(xr) - yr) ** 2).mean().backward()
+            new += list(ref.parameters())[-1].grad / world
+        assert torch.allclose(keep.grad, before + new, atol=1e-6)
+        q.put((rank, "ok", 0))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}", 0))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_hipddp_gradient_accumulation_world2():
+    res = _run(_accum_worker)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+
+
+def _val_epoch_worker(rank, world, port, q):
+    """_run_epoch('val') on two ranks: every rank issues the same collectives with the same key sets (retrieval metrics are
+    computed on the reference rank only, the other rank reports placeholders under identical keys) and all ranks end up
+    with rank 0's retrieval values and the rank-mean of the per-batch metrics.  The encoders are stubbed (no GPU here):
+    this test is about the exchange pattern of runner.py, not the kernels."""
+    try:
+        _init(rank, world, port)
+        import deepcoro_clip_amd.runner as R
+
+        class Cfg:
+            recall_k, ndcg_k = [1, 5], [5]
+            device, world_size, is_ref_device = "cpu", world, rank == 0
+            gradient_accumulation_steps, max_grad_norm, loss_name, scheduler_name, temperature = 1, 5.0, "contrastive", "", 0.07
+
+        enc = torch.nn.Linear(2, 2)
+        nb = 2 + rank  # different batch counts / sizes per rank: the gathers must cope with ragged shards
+        loader = [{"videos": torch.zeros(3 + rank, 1), "reports": [f"r{rank}b{b}s{i}" for i in range(3 + rank)]} for b in range(nb)]
+        runner = R.VideoContrastiveLearningRunner(config=Cfg(), train_loader=None, val_loader=loader, video_encoder=enc,
+                                                  text_encoder=enc, optimizer=None, log_temp=torch.zeros(1), loss_fn=None)
+        g = torch.Generator().manual_seed(5 + rank)
+
+        def fake_val_step(videos, **kw):
+            n = videos.shape[0]
+            return ({"loss": 1.0 + rank, "alignment_score": 0.5}, {"video_embeddings": torch.randn(n, 8, generator=g),
+                                                                   "text_embeddings": torch.randn(n, 8, generator=g)})
+
+        runner._val_step = fake_val_step
+        runner._preprocess_inputs = lambda batch: ({"videos": batch["videos"]}, [])
+        R.compute_similarity_matrix = lambda v, t: torch.nn.functional.normalize(v, dim=1) @ torch.nn.functional.normalize(t, dim=1).t()
+        calls = []
+
+        def fake_metrics(sim, gt):
+            calls.append(tuple(sim.shape))
+            out = {f"Recall@{k}": 0.25 * k for k in Cfg.recall_k}
+            out.update({"MRR_V2T": 0.5, "NDCG@5_V2T": 0.75, "MAP": 0.4, "MedianRank_V2T": 3})
+            return out
+
+        runner._retrieval_metrics = fake_metrics
+        out = runner._run_epoch("val", 0)
+        total = sum((3 + r) * (2 + r) for r in range(world))
+        assert (calls == [(total, total)]) if rank == 0 else (calls == []), calls
+        assert abs(out["val/loss"] - 1.5) < 1e-6 and abs(out["val/alignment_score"] - 0.5) < 1e-6
+        assert out["val/Recall@5"] == 1.25 and out["val/MRR_V2T"] == 0.5 and out["val/MedianRank_V2T"] == 3.0, out
+        q.put((rank, "ok", sorted(out)))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}", 0))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_run_epoch_val_collectives_world2():
+    res = _run(_val_epoch_worker)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    assert res[0][2] == res[1][2], "every rank must report the same metric keys"

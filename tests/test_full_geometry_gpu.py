@@ -50,7 +50,9 @@ def _oracle_run(key, build, x, gseed=1):
     return _ORACLE_CACHE[key]
 
 
-def _check_grads(prod, ref_grads, tol, relpos_tol, rope=False):
+def _check_grads(prod, ref_grads, tol, relpos_tol, rope=False, floor_frac=1e-3):
+    """Relative Frobenius error per parameter tensor; the denominator is floored at `floor_frac` x the median gradient
+    norm (bf16 rounding noise on a tensor whose own gradient is tiny scales with the activations, not with it)."""
     norms = sorted(float(g.norm()) for g in ref_grads.values() if g is not None)
     median = norms[len(norms) // 2]
     bad = []
@@ -61,13 +63,15 @@ def _check_grads(prod, ref_grads, tol, relpos_tol, rope=False):
             continue
         assert p.grad is not None, f"missing grad for {n}"
         got = p.grad.detach().cpu().double()
-        if not rope and any(k in n for k in ZERO_GRAD_KEYS):
+        # with RoPE the keys of blocks 3-15 are rotated after the pool (position dependent), so only blocks 0-2 keep the zero
+        zero = any(k in n for k in ZERO_GRAD_KEYS) and (not rope or any(f"blocks.{i}." in n for i in (0, 1, 2)))
+        if zero:
             # analytically zero: the oracle must agree (fp64 rounding only) and the HIP gradient must be noise-sized
             assert float(ref.norm()) < 1e-9 * median, (n, float(ref.norm()), median)
             assert float(got.norm()) < 0.1 * median, (n, float(got.norm()), median)
             continue
         t = relpos_tol if "rel_pos" in n else tol
-        err = ((got - ref).norm() / ref.norm().clamp_min(1e-3 * median)).item()
+        err = ((got - ref).norm() / ref.norm().clamp_min(floor_frac * median)).item()
         if not err < t:
             bad.append((n, round(err, 4)))
     assert not bad, bad[:20]
@@ -99,7 +103,7 @@ def test_video_encoder_full_geometry_fwd_and_all_grads(case, dtype, tol, gtol):
     assert out.shape == ref.shape == (c["B"], 512) and out.dtype == torch.float32
     assert _rel(out.cpu(), ref) < tol, _rel(out.cpu(), ref)
     out.backward(g.float().cuda())
-    _check_grads(prod, ref_grads, gtol, gtol * 4)
+    _check_grads(prod, ref_grads, gtol, gtol * 4, floor_frac=1e-3 if dtype == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 3e-3), (torch.bfloat16, 5e-2, 2e-1)])
@@ -122,7 +126,7 @@ def test_rope_token_output_with_gradients(T, S, N, dtype, tol, gtol):
     assert _rel(out.float().cpu(), ref) < tol, _rel(out.float().cpu(), ref)
     out.backward(g.to(out.dtype).cuda())
     # the aggregator is unused on this path: no gradients there on either side
-    _check_grads(prod, ref_grads, gtol, gtol * 4, rope=True)
+    _check_grads(prod, ref_grads, gtol, gtol * 4, rope=True, floor_frac=1e-3 if dtype == torch.float32 else 2e-2)
 
 
 def test_config4_geometry_32_frames_rope_tokens_bf16():
