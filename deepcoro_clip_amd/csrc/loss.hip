@@ -226,9 +226,71 @@ inline unsigned gsb(int64_t n) {
   return (unsigned)b;
 }
 
+// ---- multi-positive alignment diagnostics (runner.py:1298-1313 of the reference, under no_grad) --------------------------
+// one wave per video row: out[0] += sum_j logp_ij t_ij w_ij / sum_j t_ij w_ij, out[1] += [that row sum > 0],
+// out[2..3] the same with the weights replaced by 1 (the reference's fallback when every weight is zero),
+// out[4] += sum_{t_ij != 0} sim_ij, out[5] += #{t_ij != 0}, out[6] += sum_j |w_ij|.  logp = z - logsumexp_j z.
+__global__ __launch_bounds__(256) void mp_align_kernel(const float* __restrict__ z, const float* __restrict__ sim,
+                                                       const float* __restrict__ t, const float* __restrict__ w,
+                                                       int B, int M, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* zr = z + (int64_t)row * M;
+  float mx = -INFINITY;
+  for (int j = lane; j < M; j += 64) mx = fmaxf(mx, zr[j]);
+  mx = wave_max(mx);
+  float se = 0.0f;
+  for (int j = lane; j < M; j += 64) se += __expf(zr[j] - mx);
+  const float lse = mx + __logf(wave_sum(se));
+  float a_tw = 0.0f, s_tw = 0.0f, a_t = 0.0f, s_t = 0.0f, c_sum = 0.0f, c_cnt = 0.0f, w_abs = 0.0f;
+  for (int j = lane; j < M; j += 64) {
+    const int64_t i = (int64_t)row * M + j;
+    const float tv = t[i], wv = w ? w[i] : 1.0f, lp = zr[j] - lse;
+    a_tw += lp * tv * wv; s_tw += tv * wv; a_t += lp * tv; s_t += tv;
+    if (tv != 0.0f) { c_sum += sim[i]; c_cnt += 1.0f; }
+    w_abs += fabsf(wv);
+  }
+  a_tw = wave_sum(a_tw); s_tw = wave_sum(s_tw); a_t = wave_sum(a_t); s_t = wave_sum(s_t);
+  c_sum = wave_sum(c_sum); c_cnt = wave_sum(c_cnt); w_abs = wave_sum(w_abs);
+  if (lane == 0) {
+    if (s_tw > 0.0f) { atomicAdd(out + 0, a_tw / s_tw); atomicAdd(out + 1, 1.0f); }
+    if (s_t > 0.0f) { atomicAdd(out + 2, a_t / s_t); atomicAdd(out + 3, 1.0f); }
+    atomicAdd(out + 4, c_sum); atomicAdd(out + 5, c_cnt); atomicAdd(out + 6, w_abs);
+  }
+}
+
+// out = (sum |w| > 0) ? t * w : t   (reference :1276-1278: targets * positive_weights unless every weight is zero)
+__global__ void abs_sum_kernel(const float* __restrict__ w, int64_t n, float* __restrict__ out) {
+  float s = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += fabsf(w[i]);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0 && s != 0.0f) atomicAdd(out, s);
+}
+__global__ void select_mul_kernel(const float* __restrict__ t, const float* __restrict__ w, const float* __restrict__ nz,
+                                  float* __restrict__ out, int64_t n) {
+  const bool use_w = *nz > 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = use_w ? t[i] * w[i] : t[i];
+}
+
 }  // namespace
 
 #define ST (hipStream_t) stream
+
+extern "C" int dcc_mp_align(const float* z, const float* sim, const float* targets, const float* weights, int B, int M,
+                            float* out, void* stream) {
+  if (!z || !sim || !targets || !out || B <= 0 || M <= 0) return DCC_ERR_ARG;
+  hipLaunchKernelGGL(mp_align_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, z, sim, targets, weights, B, M, out);
+  return dcc_check_launch();
+}
+// nz: fp32[1] zero-initialised workspace (receives sum |weights|)
+extern "C" int dcc_mp_pos_weights(const float* targets, const float* weights, float* out, int64_t n, float* nz, void* stream) {
+  if (!targets || !weights || !out || !nz || n <= 0) return DCC_ERR_ARG;
+  hipLaunchKernelGGL(abs_sum_kernel, dim3(gsb(n)), dim3(256), 0, ST, weights, n, nz);
+  hipLaunchKernelGGL(select_mul_kernel, dim3(gsb(n)), dim3(256), 0, ST, targets, weights, nz, out, n);
+  return dcc_check_launch();
+}
 
 extern "C" int dcc_l2norm_fwd(const float* x, int64_t ldx, float* y, float* norms, int R, int D, float eps,
                               float* norm_sum, void* stream) {

@@ -108,8 +108,10 @@ class ZeroArena:
         n = 1
         for d in shape:
             n *= int(d)
+        if not self.active:
+            return torch.zeros(shape, device=device, dtype=torch.float32)
         n4 = (n + 3) // 4 * 4  # keep every slice 16-byte aligned
-        if self.active and self.buf is not None and self.buf.device == device and self.off + n4 <= self.buf.numel():
+        if self.buf is not None and self.buf.device == device and self.off + n4 <= self.buf.numel():
             t = self.buf[self.off:self.off + n].view(shape)
             self.off += n4
             self.high = max(self.high, self.off)

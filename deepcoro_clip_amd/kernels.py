@@ -661,3 +661,24 @@ def bce(z, y, pw, pos_weight: float, neg_weight: float, thr: float, denom_host: 
     L.call("dcc_bce", L.ptr(z), L.ptr(y), L.ptr(pw), float(pos_weight), float(neg_weight), float(thr),
            float(denom_host), L.ptr(denom_dev), L.ptr(dz), z.numel(), L.ptr(scal), L.stream())
     return dz
+
+
+def mp_align(z, sim, targets, weights=None) -> torch.Tensor:
+    """Multi-positive alignment sums (see include/dcc.h): fp32[8] on the device."""
+    L.require_cuda(z, sim, targets, weights)
+    B, M = z.shape
+    assert sim.shape == (B, M) and targets.shape == (B, M) and z.is_contiguous() and sim.is_contiguous() and targets.is_contiguous()
+    assert weights is None or (weights.shape == (B, M) and weights.is_contiguous() and weights.dtype == torch.float32)
+    out = torch.zeros(8, device=z.device, dtype=torch.float32)
+    L.call("dcc_mp_align", L.ptr(z), L.ptr(sim), L.ptr(targets), L.ptr(weights), B, M, L.ptr(out), L.stream())
+    return out
+
+
+def mp_pos_weights(targets, weights) -> torch.Tensor:
+    """targets * weights, or targets when every weight is zero (decided on the device)."""
+    L.require_cuda(targets, weights)
+    assert targets.shape == weights.shape and targets.is_contiguous() and weights.is_contiguous()
+    out = torch.empty_like(targets)
+    nz = torch.zeros(1, device=targets.device, dtype=torch.float32)
+    L.call("dcc_mp_pos_weights", L.ptr(targets), L.ptr(weights), L.ptr(out), targets.numel(), L.ptr(nz), L.stream())
+    return out

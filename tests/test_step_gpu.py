@@ -292,3 +292,121 @@ def test_ddp_wrapped_step_writes_gradients_into_the_arena_and_matches_plain_step
     assert len(_grad_slots._TAKEN) >= n_lin, (len(_grad_slots._TAKEN), n_lin)  # Linear weights + biases were written in place
     for (n, p), (_, q) in zip(plain.text_encoder.named_parameters(), te.module.named_parameters()):
         assert torch.allclose(p, q, rtol=1e-3, atol=1e-5), n
+
+
+@pytest.mark.parametrize("loss_name", ["contrastive", "siglip"])
+def test_embedding_cache_two_pass_equals_one_shot(loss_name):
+    """BASELINE configs[3] mechanism (global batch 4096 = 512 studies per rank through an embedding cache): B = 32 in 4
+    micro-batches of 8 against the one-shot step — same loss (<= 1e-6) and the same parameter gradients (fp32 compute)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import make_tiny_setup
+
+    B = 32
+    ra, _, (videos, ids, mask) = make_tiny_setup(torch.float32, B=B, loss_name=loss_name)
+    rb, _, _ = make_tiny_setup(torch.float32, B=B, loss_name=loss_name)
+    mask[3, 9:] = 0
+    args = (videos.cuda(), ids.cuda(), mask.cuda(), None, None, None, 1)
+    la, va, ta, _ = ra._forward_backward(*args)
+    lb, vb, tb, _ = rb._forward_backward_cached(*args, 8)
+    assert abs(la.item() - lb.item()) <= 1e-6 * max(1.0, abs(la.item())), (la.item(), lb.item())
+    assert torch.allclose(va.detach(), vb, atol=1e-6) and torch.allclose(ta.detach(), tb, atol=1e-6)
+    worst = 0.0
+    pa = dict(ra.video_encoder.named_parameters()) | {"text." + k: v for k, v in ra.text_encoder.named_parameters()}
+    pb = dict(rb.video_encoder.named_parameters()) | {"text." + k: v for k, v in rb.text_encoder.named_parameters()}
+    norms = sorted(float(p.grad.norm()) for p in pa.values() if p.grad is not None)
+    floor = 1e-3 * norms[len(norms) // 2]
+    for n, p in pa.items():
+        if p.grad is None:
+            assert pb[n].grad is None or float(pb[n].grad.abs().max()) == 0.0, n
+            continue
+        err = float((p.grad - pb[n].grad).norm() / p.grad.norm().clamp_min(floor))
+        worst = max(worst, err)
+        assert err < 2e-4, (n, err)
+    assert abs(ra.log_temp.grad.item() - rb.log_temp.grad.item()) < 1e-5 * max(1.0, abs(ra.log_temp.grad.item()))
+    print(f"[embedding cache] worst relative gradient deviation {worst:.2e}")
+    # through the public entry point: config switch, optimizer step, metric keys
+    rb.config.embedding_cache_micro_batch = 8
+    m, emb = rb._train_step(videos=videos.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda())
+    assert math.isfinite(m["loss"]) and emb["video_embeddings"].shape == (B, 512) and "alignment_score" in m
+
+
+def test_embedding_cache_redraws_the_same_masks():
+    """With every stochastic layer on (dropout 0.2, stochastic depth 0.2) the re-forward of pass 3 must reproduce the
+    cached embeddings of pass 1 exactly (same dropout call-site seeds + step counter, rewound device generator)."""
+    from deepcoro_clip_amd.losses import Loss
+    from deepcoro_clip_amd.optim import HipAdamW
+    from deepcoro_clip_amd.registry import LossRegistry, register_submodules
+    from deepcoro_clip_amd.runner import VideoContrastiveLearningRunner
+    from deepcoro_clip_amd.text_encoder import TextEncoder
+    from deepcoro_clip_amd.video_encoder import VideoEncoder
+
+    register_submodules("deepcoro_clip_amd")
+    torch.manual_seed(0)
+    ve = VideoEncoder(num_frames=4, spatial_size=(64, 64), pretrained=False, freeze_ratio=1.0, dropout=0.2,
+                      token_pooling_mode="attention", attention_pool_dropout=0.1, compute_dtype=torch.float32).cuda().train()
+    te = TextEncoder(dropout=0.2, freeze_ratio=0.0, compute_dtype=torch.float32,
+                     bert_config=dict(vocab_size=512, num_hidden_layers=2, max_position_embeddings=64)).cuda().train()
+    lt = torch.nn.Parameter(torch.log(torch.tensor([0.07], device="cuda")))
+    opt = HipAdamW([{"params": list(ve.model.parameters()) + list(ve.attention_pool.parameters()) + list(ve.aggregator.parameters())
+                     + list(te.parameters()) + [lt], "lr": 1e-4}], lr=1e-4)
+    cfg = type("C", (), dict(recall_k=[1], ndcg_k=[5], device="cuda:0", world_size=1, gradient_accumulation_steps=1,
+                             max_grad_norm=5.0, is_ref_device=True, loss_name="siglip", scheduler_name="", temperature=0.07,
+                             embedding_cache_micro_batch=4))()
+    r = VideoContrastiveLearningRunner(config=cfg, video_encoder=ve, text_encoder=te, optimizer=opt, log_temp=lt,
+                                       loss_fn=Loss(loss_type=LossRegistry.get("siglip")()))
+    r._cache_check = True
+    g = torch.Generator().manual_seed(3)
+    videos = torch.randn(12, 2, 4, 64, 64, 3, generator=g).cuda()
+    ids = torch.randint(0, 512, (12, 16), generator=g).cuda()
+    mask = torch.ones(12, 16, dtype=torch.int64).cuda()
+    for _ in range(2):
+        m, _ = r._train_step(videos=videos, input_ids=ids, attention_mask=mask)
+        assert math.isfinite(m["loss"])
+    assert r._cache_maxdiff == 0.0, r._cache_maxdiff
+
+
+@pytest.mark.parametrize("weighted,zero_weights", [(False, False), (True, False), (True, True)])
+def test_multi_positive_alignment_metrics_match_reference_formulas(weighted, zero_weights):
+    """The runner's inline multi-positive SigLIP branch (reference runner.py:1256-1313): alignment_logprob = mean over
+    rows with positives of sum_j log_softmax(logits)_ij * w_ij / sum_j w_ij with w = positive_weights * mask (the plain
+    mask when every weight is zero), alignment_cosine = mean cosine over the positives; M != B texts."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import make_tiny_setup
+    import torch.nn.functional as F
+
+    B, M = 4, 6
+    runner, _, (videos, _, _) = make_tiny_setup(torch.float32, B=B, loss_name="siglip")
+    runner.use_weighted_siglip = weighted
+    if weighted:
+        from deepcoro_clip_amd.losses import WeightedSigLIPLoss
+        runner.weighted_siglip_loss = WeightedSigLIPLoss()
+    g = torch.Generator().manual_seed(21)
+    ids = torch.randint(0, 512, (M, 16), generator=g)
+    mask = torch.ones(M, 16, dtype=torch.int64)
+    pm = torch.zeros(B, M)
+    pm[0, 0] = pm[0, 4] = pm[1, 1] = pm[2, 2] = pm[2, 3] = pm[2, 5] = 1.0  # row 3 has no positive
+    pw = torch.zeros(B, M) if zero_weights else (torch.rand(B, M, generator=g) * 9 + 1)
+    m, emb = runner._train_step(videos=videos.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda(),
+                                positive_mask=pm.cuda(), positive_weights=pw.cuda())
+    v, t = emb["video_embeddings"].cpu().double(), emb["text_embeddings"].cpu().double()
+    sim = F.normalize(v, dim=1) @ F.normalize(t, dim=1).t()
+    logits = sim * torch.sigmoid(sim) / 0.07
+    logp = F.log_softmax(logits, dim=1)
+    wmask = (pw * pm).double() if torch.count_nonzero(pw) > 0 else pm.double()
+    rs = wmask.sum(1)
+    valid = rs > 0
+    ref_lp = ((logp * (wmask / rs.clamp_min(1e-30)[:, None])).sum(1)[valid]).mean().item()
+    ref_cos = sim[pm.bool()].mean().item()
+    assert abs(m["alignment_logprob"] - ref_lp) < 1e-4 * max(1.0, abs(ref_lp)), (m["alignment_logprob"], ref_lp)
+    assert abs(m["alignment_score"] - math.exp(ref_lp)) < 1e-4
+    assert abs(m["alignment_cosine"] - ref_cos) < 1e-5
+    # loss value of the branch against the same formulas
+    if weighted:
+        posw = wmask
+        row = -(logp * posw).sum(1) / posw.sum(1).clamp_min(1e-6)
+        logp_c = F.log_softmax(logits.t(), dim=1)
+        col = -(logp_c * posw.t()).sum(1) / posw.t().sum(1).clamp_min(1e-6)
+        ref_loss = 0.5 * (row.mean() + col.mean()).item()  # utils/loss/weighted_siglip.py:41-51: plain means
+        assert abs(m["loss"] - ref_loss) < 2e-4 * max(1.0, abs(ref_loss)), (m["loss"], ref_loss)
