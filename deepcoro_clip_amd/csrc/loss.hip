@@ -274,9 +274,194 @@ __global__ void select_mul_kernel(const float* __restrict__ t, const float* __re
     out[i] = use_w ? t[i] * w[i] : t[i];
 }
 
+// ---- auto-balanced positive weights (utils/loss/contrastive.py:291-296, siglip_pairwise.py:161-166) ---------------------
+// out[i][j] = max((T - n_i) / n_i, 1) with n_i = max(sum_j counts[i][j], 1): one wave per row
+__global__ __launch_bounds__(256) void auto_balance_kernel(const float* __restrict__ counts, float* __restrict__ out, int B, int T) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float n = 0.0f;
+  for (int j = lane; j < T; j += 64) n += counts[(int64_t)row * T + j];
+  n = fmaxf(wave_sum(n), 1.0f);
+  const float ratio = fmaxf(((float)T - n) / n, 1.0f);
+  for (int j = lane; j < T; j += 64) out[(int64_t)row * T + j] = ratio;
+}
+
+// ---- entropy regulariser (utils/loss/contrastive.py:19-68): L_ent = relu(thr - mean_i H_i), H_i = -sum_j p_ij log(p_ij + 1e-10)
+// pass 1: row entropies -> ent[0] += H_i, ent[1] = min, ent[2] = max (atomics on the bit patterns of non-negative floats)
+__global__ __launch_bounds__(256) void entropy_rows_kernel(const float* __restrict__ z, int B, int M, float* __restrict__ ent) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* zr = z + (int64_t)row * M;
+  float mx = -INFINITY;
+  for (int j = lane; j < M; j += 64) mx = fmaxf(mx, zr[j]);
+  mx = wave_max(mx);
+  float se = 0.0f;
+  for (int j = lane; j < M; j += 64) se += __expf(zr[j] - mx);
+  const float inv = 1.0f / wave_sum(se);
+  float h = 0.0f;
+  for (int j = lane; j < M; j += 64) {
+    const float p = __expf(zr[j] - mx) * inv;
+    h -= p * __logf(p + 1e-10f);
+  }
+  h = wave_sum(h);
+  if (lane == 0) {
+    atomicAdd(ent + 0, h);
+    const float hc = fmaxf(h, 0.0f);  // H >= 0 up to rounding: integer order == float order
+    atomicMin(reinterpret_cast<unsigned*>(ent + 1), __float_as_uint(hc));
+    atomicMax(reinterpret_cast<unsigned*>(ent + 2), __float_as_uint(hc));
+  }
+}
+// pass 2: scal[0] += weight * deficit; dz_ij += weight / B * p_ij (g_ij - sum_k p_ik g_ik), g = log(p + eps) + p / (p + eps),
+// only while the deficit is positive (decided on the device)
+__global__ __launch_bounds__(256) void entropy_grad_kernel(const float* __restrict__ z, float* __restrict__ dz, int B, int M,
+                                                           float weight, float thr, const float* __restrict__ ent,
+                                                           float* __restrict__ scal) {
+  const float deficit = thr - ent[0] / (float)B;
+  if (deficit <= 0.0f) return;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  if (row == 0 && lane == 0) atomicAdd(scal + 0, weight * deficit);
+  if (!dz) return;
+  const float* zr = z + (int64_t)row * M;
+  float mx = -INFINITY;
+  for (int j = lane; j < M; j += 64) mx = fmaxf(mx, zr[j]);
+  mx = wave_max(mx);
+  float se = 0.0f;
+  for (int j = lane; j < M; j += 64) se += __expf(zr[j] - mx);
+  const float inv = 1.0f / wave_sum(se);
+  float gb = 0.0f;
+  for (int j = lane; j < M; j += 64) {
+    const float p = __expf(zr[j] - mx) * inv;
+    gb += p * (__logf(p + 1e-10f) + p / (p + 1e-10f));
+  }
+  gb = wave_sum(gb);
+  const float c = weight / (float)B;
+  for (int j = lane; j < M; j += 64) {
+    const float p = __expf(zr[j] - mx) * inv;
+    dz[(int64_t)row * M + j] += c * p * (__logf(p + 1e-10f) + p / (p + 1e-10f) - gb);
+  }
+}
+
+// ---- symmetric multi-positive InfoNCE on given logits (utils/loss/multi_positive_infonce.py:9-110) -----------------------
+// per-row / per-column weighted CE with the weights normalised by max(sum, 1); rows / columns without a positive in the
+// MASK are left out; reduction over the concatenation of the selected rows and columns (mean | sum | importance-weighted).
+// Kernel 1 (one block): coefficient of every row / column + the scalar loss, from the per-row statistics.
+//   wsum_r/c: sum of clamped weights, msum_r/c: sum of the mask, imp_r/c: importance base sums (nullable),
+//   nll_r/c: -sum_j w_ij logp_ij (unnormalised).  coef_r[i] = multiplier of loss_i in the total (0 when not selected).
+__global__ __launch_bounds__(256) void mpnce_coef_kernel(const float* wsum_r, const float* msum_r, const float* imp_r,
+                                                         const float* nll_r, float* coef_r, int N, const float* wsum_c,
+                                                         const float* msum_c, const float* imp_c, const float* nll_c,
+                                                         float* coef_c, int M, int mean, float imp_eps, float* scal) {
+  __shared__ float red[2][4];
+  float cnt = 0.0f, tw = 0.0f;
+  const bool use_imp = imp_r != nullptr;
+  for (int i = threadIdx.x; i < N + M; i += 256) {
+    const bool row = i < N;
+    const int k = row ? i : i - N;
+    const bool sel = (row ? msum_r[k] : msum_c[k]) > 0.0f;
+    if (sel) { cnt += 1.0f; if (use_imp) tw += fmaxf(row ? imp_r[k] : imp_c[k], imp_eps); }
+  }
+  cnt = wave_sum(cnt); tw = wave_sum(tw);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cnt; red[1][threadIdx.x >> 6] = tw; }
+  __syncthreads();
+  cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  tw = fmaxf(red[1][0] + red[1][1] + red[1][2] + red[1][3], imp_eps);
+  float loss = 0.0f;
+  for (int i = threadIdx.x; i < N + M; i += 256) {
+    const bool row = i < N;
+    const int k = row ? i : i - N;
+    const bool sel = (row ? msum_r[k] : msum_c[k]) > 0.0f;
+    float c = 0.0f;
+    if (sel) {
+      if (use_imp) c = fmaxf(row ? imp_r[k] : imp_c[k], imp_eps) / (mean ? tw : 1.0f);
+      else c = mean ? 1.0f / cnt : 1.0f;
+    }
+    const float li = (row ? nll_r[k] : nll_c[k]) / fmaxf(row ? wsum_r[k] : wsum_c[k], 1.0f);
+    (row ? coef_r : coef_c)[k] = c;
+    loss += c * li;
+  }
+  loss = wave_sum(loss);
+  if ((threadIdx.x & 63) == 0) atomicAdd(scal + 0, loss);
+}
+// Kernel 0: nll_r[i] += -w_ij (z_ij - lse_r[i]), nll_c[j] likewise (atomics; matrices here are a few hundred squared)
+__global__ void mpnce_nll_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ lse_r,
+                                 const float* __restrict__ lse_c, float* __restrict__ nll_r, float* __restrict__ nll_c, int N, int M) {
+  const int64_t n = (int64_t)N * M;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = i / M, c = i % M;
+    const float wv = fmaxf(w[i], 0.0f);
+    if (wv != 0.0f) { atomicAdd(nll_r + r, -wv * (z[i] - lse_r[r])); atomicAdd(nll_c + c, -wv * (z[i] - lse_c[c])); }
+  }
+}
+// Kernel 2: dz_ij = coef_r[i] (p_row_ij W_i - w_ij) / max(W_i, 1) + coef_c[j] (p_col_ij C_j - w_ij) / max(C_j, 1)
+__global__ void mpnce_grad_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ lse_r,
+                                  const float* __restrict__ lse_c, const float* __restrict__ wsum_r, const float* __restrict__ wsum_c,
+                                  const float* __restrict__ coef_r, const float* __restrict__ coef_c, float* __restrict__ dz, int N, int M) {
+  const int64_t n = (int64_t)N * M;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = i / M, c = i % M;
+    const float wv = fmaxf(w[i], 0.0f), v = z[i];
+    dz[i] = coef_r[r] * (__expf(v - lse_r[r]) * wsum_r[r] - wv) / fmaxf(wsum_r[r], 1.0f) +
+            coef_c[c] * (__expf(v - lse_c[c]) * wsum_c[c] - wv) / fmaxf(wsum_c[c], 1.0f);
+  }
+}
+
 }  // namespace
 
 #define ST (hipStream_t) stream
+
+// out = max(a * b, 0) (b nullable: max(a, 0)) — the clamped positive weights of the multi-positive losses
+__global__ void mul_clamp0_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = fmaxf(b ? a[i] * b[i] : a[i], 0.0f);
+}
+extern "C" int dcc_mul_clamp0(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  if (!a || !out || n <= 0) return DCC_ERR_ARG;
+  hipLaunchKernelGGL(mul_clamp0_kernel, dim3(gsb(n)), dim3(256), 0, ST, a, b, out, n);
+  return dcc_check_launch();
+}
+__global__ void clamp_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float lo, float hi) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = fminf(fmaxf(x[i], lo), hi);
+}
+extern "C" int dcc_clamp(const float* x, float* out, int64_t n, float lo, float hi, void* stream) {
+  if (!x || !out || n <= 0) return DCC_ERR_ARG;
+  hipLaunchKernelGGL(clamp_kernel, dim3(gsb(n)), dim3(256), 0, ST, x, out, n, lo, hi);
+  return dcc_check_launch();
+}
+extern "C" int dcc_auto_balance_weights(const float* counts, float* out, int B, int T, void* stream) {
+  if (!counts || !out || B <= 0 || T <= 0) return DCC_ERR_ARG;
+  hipLaunchKernelGGL(auto_balance_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, counts, out, B, T);
+  return dcc_check_launch();
+}
+// ent: fp32[4] workspace initialised by the caller to {0, +inf, 0, 0}; afterwards {sum_i H_i, min_i H_i, max_i H_i, -}.
+// scal[0] += weight * relu(thr - mean H); dz (nullable) += its gradient.
+extern "C" int dcc_entropy_reg(const float* z, float* dz, int B, int M, float weight, float thr, float* ent, float* scal,
+                               void* stream) {
+  if (!z || !ent || !scal || B <= 0 || M <= 0) return DCC_ERR_ARG;
+  hipLaunchKernelGGL(entropy_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, z, B, M, ent);
+  hipLaunchKernelGGL(entropy_grad_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, z, dz, B, M, weight, thr, ent, scal);
+  return dcc_check_launch();
+}
+// ws: fp32 workspace of 2 * (N + M) zero-initialised floats (nll_r, nll_c, coef_r, coef_c)
+extern "C" int dcc_mp_infonce(const float* z, const float* w, const float* lse_r, const float* lse_c, const float* wsum_r,
+                              const float* wsum_c, const float* msum_r, const float* msum_c, const float* imp_r,
+                              const float* imp_c, float* ws, float* dz, int N, int M, int mean, float imp_eps, float* scal,
+                              void* stream) {
+  if (!z || !w || !lse_r || !lse_c || !wsum_r || !wsum_c || !msum_r || !msum_c || !ws || !scal || N <= 0 || M <= 0) return DCC_ERR_ARG;
+  if ((imp_r == nullptr) != (imp_c == nullptr)) return DCC_ERR_ARG;
+  float *nll_r = ws, *nll_c = ws + N, *coef_r = ws + N + M, *coef_c = ws + 2 * N + M;
+  hipLaunchKernelGGL(mpnce_nll_kernel, dim3(gsb((int64_t)N * M)), dim3(256), 0, ST, z, w, lse_r, lse_c, nll_r, nll_c, N, M);
+  hipLaunchKernelGGL(mpnce_coef_kernel, dim3(1), dim3(256), 0, ST, wsum_r, msum_r, imp_r, nll_r, coef_r, N, wsum_c, msum_c,
+                     imp_c, nll_c, coef_c, M, mean, imp_eps, scal);
+  if (dz)
+    hipLaunchKernelGGL(mpnce_grad_kernel, dim3(gsb((int64_t)N * M)), dim3(256), 0, ST, z, w, lse_r, lse_c, wsum_r, wsum_c,
+                       coef_r, coef_c, dz, N, M);
+  return dcc_check_launch();
+}
 
 extern "C" int dcc_mp_align(const float* z, const float* sim, const float* targets, const float* weights, int B, int M,
                             float* out, void* stream) {

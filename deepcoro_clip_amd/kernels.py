@@ -682,3 +682,56 @@ def mp_pos_weights(targets, weights) -> torch.Tensor:
     nz = torch.zeros(1, device=targets.device, dtype=torch.float32)
     L.call("dcc_mp_pos_weights", L.ptr(targets), L.ptr(weights), L.ptr(out), targets.numel(), L.ptr(nz), L.stream())
     return out
+
+
+def mul_clamp0(a: torch.Tensor, b: torch.Tensor | None = None) -> torch.Tensor:
+    L.require_cuda(a, b)
+    assert a.dtype == torch.float32 and a.is_contiguous() and (b is None or (b.shape == a.shape and b.is_contiguous() and b.dtype == torch.float32))
+    out = torch.empty_like(a)
+    L.call("dcc_mul_clamp0", L.ptr(a), L.ptr(b), L.ptr(out), a.numel(), L.stream())
+    return out
+
+
+def auto_balance_weights(counts: torch.Tensor) -> torch.Tensor:
+    """[B, T] matrix whose row i holds max((T - n_i) / n_i, 1), n_i = max(sum_j counts[i, j], 1)."""
+    L.require_cuda(counts)
+    assert counts.dim() == 2 and counts.dtype == torch.float32 and counts.is_contiguous()
+    out = torch.empty_like(counts)
+    L.call("dcc_auto_balance_weights", L.ptr(counts), L.ptr(out), counts.shape[0], counts.shape[1], L.stream())
+    return out
+
+
+def entropy_reg(z: torch.Tensor, dz: torch.Tensor | None, weight: float, thr: float, scal: torch.Tensor) -> torch.Tensor:
+    """scal[0] += weight * relu(thr - mean row entropy of softmax(z)); dz += gradient.  Returns ent = {sum H, min H, max H, -}."""
+    L.require_cuda(z, dz, scal)
+    B, M = z.shape
+    ent = torch.tensor([0.0, float("inf"), 0.0, 0.0], dtype=torch.float32).to(z.device, non_blocking=True)
+    L.call("dcc_entropy_reg", L.ptr(z), L.ptr(dz), B, M, float(weight), float(thr), L.ptr(ent), L.ptr(scal), L.stream())
+    return ent
+
+
+def mp_infonce(z, w, mask, imp_base, mean: bool, scal, want_grad: bool = True):
+    """Symmetric multi-positive InfoNCE on logits (see include/dcc.h).  w: clamped weights; imp_base: None or [N, M]."""
+    L.require_cuda(z, w, mask, imp_base, scal)
+    N, M = z.shape
+    lr, lc = lse(z)
+    wr, wc = rowcol_sums(w)
+    mr, mc = rowcol_sums(mask)
+    ir = ic = None
+    if imp_base is not None:
+        ir, ic = rowcol_sums(imp_base)
+    ws = torch.zeros(2 * (N + M), device=z.device, dtype=torch.float32)
+    dz = torch.empty_like(z) if want_grad else None
+    L.call("dcc_mp_infonce", L.ptr(z), L.ptr(w), L.ptr(lr), L.ptr(lc), L.ptr(wr), L.ptr(wc), L.ptr(mr), L.ptr(mc), L.ptr(ir),
+           L.ptr(ic), L.ptr(ws), L.ptr(dz), N, M, int(mean), float(torch.finfo(torch.float32).eps), L.ptr(scal), L.stream())
+    return dz
+
+
+def clamp01(x: torch.Tensor) -> torch.Tensor:
+    """clamp(x, 0, 1) of a small fp32 mask (targets of the BCE losses)."""
+    L.require_cuda(x)
+    x = x.contiguous()
+    assert x.dtype == torch.float32
+    out = torch.empty_like(x)
+    L.call("dcc_clamp", L.ptr(x), L.ptr(out), x.numel(), 0.0, 1.0, L.stream())
+    return out

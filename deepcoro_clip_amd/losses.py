@@ -68,8 +68,17 @@ class PairLossFn(torch.autograd.Function):
             y = opts["targets"].contiguous().float()
             pw = opts.get("pos_weights")
             pw = pw.contiguous().float() if pw is not None else None
-            dz = K.bce(z, y, pw, opts.get("positive_weight", 1.0), opts.get("negative_weight", 1.0), opts.get("thr", 0.5),
+            pos_w = opts.get("positive_weight", 1.0)
+            if opts.get("auto_balance_counts") is not None:  # positives weighted by the row's negative / positive ratio
+                pw, pos_w = K.auto_balance_weights(opts["auto_balance_counts"].contiguous().float()), 1.0
+            dz = K.bce(z, y, pw, pos_w, opts.get("negative_weight", 1.0), opts.get("thr", 0.5),
                        opts.get("denom_host", float(B * M)), opts.get("denom_dev"), scal, want_grad)
+            if opts.get("entropy_weight") is not None:  # + entropy_weight * relu(min_entropy - mean row entropy)
+                bce_only = scal[0:1].clone()
+                ent = K.entropy_reg(z, dz, opts["entropy_weight"], opts["min_entropy_threshold"], scal)
+                if opts.get("entropy_out") is not None:
+                    opts["entropy_out"].update({"ent": ent, "bce": bce_only, "total": scal, "B": B, "M": M,
+                                                "weight": opts["entropy_weight"], "thr": opts["min_entropy_threshold"]})
         if opts.get("diag_out") is not None:  # runner diagnostics (no extra GEMM / no extra host sync)
             opts["diag_out"].update({"sim": sim, "logits": z, "lse_rows": lr, "scal": scal, "video_norms": vn,
                                      "text_norms": tn})
@@ -229,11 +238,9 @@ class SigLIPLoss(nn.Module):
         self.positive_weight = max(float(positive_weight), 1e-6)
         self.negative_weight = max(float(negative_weight), 1e-6)
         self.use_severity_weights = use_severity_weights
-        if auto_balance or entropy_regularization:
-            raise NotImplementedError("auto_balance / entropy_regularization are off by default in the reference and "
-                                      "not implemented on the HIP path")
         self.auto_balance, self.entropy_regularization = auto_balance, entropy_regularization
         self.entropy_weight, self.min_entropy_threshold = entropy_weight, min_entropy_threshold
+        self._entropy_raw: dict = {}
         if learnable_bias:
             self.bias = nn.Parameter(torch.tensor(bias_init))
         else:
@@ -249,12 +256,123 @@ class SigLIPLoss(nn.Module):
             targets = torch.zeros((B, T), device=v.device, dtype=torch.float32)
             targets[:m, :m] = torch.eye(m, device=v.device)  # constant target construction (no arithmetic on data)
         else:
-            targets = pos_mask.float().clamp(0.0, 1.0)
+            targets = K.clamp01(pos_mask.float())
         pw = pos_weights if (self.use_severity_weights and pos_weights is not None) else None
         bias = self.bias if self.bias.is_cuda else self.bias.to(v.device)
+        extra = _entropy_opts(self)
+        if self.auto_balance:
+            extra["auto_balance_counts"] = targets
         return pair_loss(v, t, _lt(log_temp, v), bias, mode=MODE_BIAS_CLAMP, kind=KIND_BCE, clamp_temp=True,
                          targets=targets, pos_weights=pw, positive_weight=self.positive_weight,
-                         negative_weight=self.negative_weight, thr=0.5, denom_host=float(B * T))
+                         negative_weight=self.negative_weight, thr=0.5, denom_host=float(B * T), **extra)
+
+    def get_entropy_diagnostics(self) -> dict:
+        return _entropy_diagnostics(self._entropy_raw)
+
+
+def _entropy_opts(mod) -> dict:
+    if not mod.entropy_regularization:
+        return {}
+    mod._entropy_raw = {}
+    return {"entropy_weight": float(mod.entropy_weight), "min_entropy_threshold": float(mod.min_entropy_threshold),
+            "entropy_out": mod._entropy_raw}
+
+
+def _entropy_diagnostics(raw: dict) -> dict:
+    """The reference's diagnostics dict (utils/loss/contrastive.py:57-63, 306-313); resolved on request (one host read)
+    instead of six `.item()` syncs inside every forward."""
+    if not raw:
+        return {}
+    import math as _m
+
+    s, mn, mx, _ = raw["ent"].tolist()
+    mean = s / raw["B"]
+    deficit = max(0.0, raw["thr"] - mean)
+    return {"entropy_mean": mean, "entropy_min": mn, "entropy_max": mx, "entropy_normalized": mean / _m.log(raw["M"]),
+            "entropy_deficit": deficit, "bce_loss": float(raw["bce"].item()), "entropy_loss": raw["weight"] * deficit}
+
+
+class SiglipPairwiseFeatureLoss(nn.Module):
+    """utils/loss/siglip_pairwise.py:261-376: sigmoid-BCE on clamp(cos / exp(log_temp), +-30) (no bias, no temperature
+    clamp) with multi-positive masks, per-pair weights, auto positive weighting and the entropy regulariser; the video
+    side, the mask and the weights are gathered under DDP."""
+
+    def __init__(self, *, positive_weight: float = 1.0, negative_weight: float = 1.0, use_positive_weights: bool = True,
+                 auto_positive_weight: bool = False, entropy_regularization: bool = False, entropy_weight: float = 0.1,
+                 min_entropy_threshold: float = 2.0) -> None:
+        super().__init__()
+        self.positive_weight = max(float(positive_weight), 1e-6)
+        self.negative_weight = max(float(negative_weight), 0.0)
+        self.use_positive_weights = use_positive_weights
+        self.auto_positive_weight = auto_positive_weight
+        self.entropy_regularization = entropy_regularization
+        self.entropy_weight, self.min_entropy_threshold = entropy_weight, min_entropy_threshold
+        self._entropy_raw: dict = {}
+
+    def forward(self, video_features, text_features, log_temp, pos_mask, pos_weights=None):
+        v = gather_all(video_features)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            pos_mask = gather_all(pos_mask.contiguous())
+            pos_weights = gather_all(pos_weights.contiguous()) if pos_weights is not None else None
+        B, T = v.shape[0], text_features.shape[0]
+        mask = pos_mask.float().contiguous()
+        targets = K.clamp01(mask)
+        pw = pos_weights.float().contiguous() if (self.use_positive_weights and pos_weights is not None) else None
+        extra = _entropy_opts(self)
+        if self.auto_positive_weight:
+            extra["auto_balance_counts"] = mask
+        # weights follow pos_mask > 0 (thr = 0 on the clamped targets: identical set for non-negative masks)
+        return pair_loss(v, text_features, _lt(log_temp, v), None, mode=MODE_BIAS_CLAMP, kind=KIND_BCE, clamp_temp=False,
+                         targets=targets, pos_weights=pw, positive_weight=self.positive_weight,
+                         negative_weight=self.negative_weight, thr=0.0, denom_host=float(B * T), **extra)
+
+    def get_entropy_diagnostics(self) -> dict:
+        return _entropy_diagnostics(self._entropy_raw)
+
+
+class _MultiPositiveInfoNCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, pos_mask, pos_weights, mean, use_imp):
+        L.require_cuda(logits, pos_mask, pos_weights)
+        z = logits.detach().float().contiguous()
+        mask = pos_mask.detach().float().contiguous()
+        pw = pos_weights.detach().float().contiguous() if pos_weights is not None else None
+        w = K.mul_clamp0(mask, pw)
+        base = (pw if pw is not None else mask) if use_imp else None
+        scal = torch.zeros(8, device=z.device, dtype=torch.float32)
+        dz = K.mp_infonce(z, w, mask, base, mean, scal, want_grad=ctx.needs_input_grad[0])
+        if dz is not None:
+            ctx.save_for_backward(dz)
+        ctx.dt = logits.dtype
+        return scal[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        dz = _scale_by(dz, g.detach().reshape(1).float().contiguous())
+        return (dz if ctx.dt == torch.float32 else K.cast(dz, ctx.dt)), None, None, None, None
+
+
+@LossRegistry.register("multi_positive_infonce")
+class MultiPositiveInfoNCELoss(nn.Module):
+    """Symmetric multi-positive InfoNCE on given logits (utils/loss/multi_positive_infonce.py:9-110): rows / columns
+    without positives are skipped, each selected row's weights are normalised by max(sum, 1); returns 0 when nothing is
+    selected.  reduction 'mean' | 'sum', optional importance weighting of rows / columns."""
+
+    def __init__(self, reduction: str = "mean", use_importance_weighting: bool = False):
+        super().__init__()
+        if reduction not in {"mean", "sum"}:
+            raise ValueError(f"Unsupported reduction '{reduction}'. Expected 'mean' or 'sum'.")
+        self.reduction, self.use_importance_weighting = reduction, use_importance_weighting
+
+    def forward(self, logits, pos_mask, pos_weights=None):
+        if logits.dim() != 2:
+            raise ValueError(f"logits must be 2D, got shape {tuple(logits.shape)}")
+        if pos_mask.shape != logits.shape:
+            raise ValueError("pos_mask must match logits shape.")
+        if pos_weights is not None and pos_weights.shape != logits.shape:
+            raise ValueError("pos_weights must match logits shape.")
+        return _MultiPositiveInfoNCEFn.apply(logits, pos_mask, pos_weights, self.reduction == "mean", self.use_importance_weighting)
 
 
 class WeightedSigLIPLoss(nn.Module):

@@ -183,6 +183,24 @@ int dcc_bce(const float* z, const float* y, const float* pw, float pos_weight, f
  * sum of cosines over the positives, #positives, sum |w|}.  weights may be NULL. */
 int dcc_mp_align(const float* z, const float* sim, const float* targets, const float* weights, int B, int M, float* out,
                  void* stream);
+/* out = max(a * b, 0), b nullable (clamped positive weights, utils/loss/multi_positive_infonce.py:22-26,52). */
+int dcc_mul_clamp0(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* out = clamp(x, lo, hi) (BCE targets: pos_mask.clamp(0, 1), utils/loss/contrastive.py:284). */
+int dcc_clamp(const float* x, float* out, int64_t n, float lo, float hi, void* stream);
+/* Auto-balanced positive weights: out[i][:] = max((T - n_i) / n_i, 1), n_i = max(sum_j counts[i][j], 1)
+ * (utils/loss/contrastive.py:291-296, utils/loss/siglip_pairwise.py:161-166). */
+int dcc_auto_balance_weights(const float* counts, float* out, int B, int T, void* stream);
+/* Entropy regulariser on logits z [B,M] (utils/loss/contrastive.py:19-68): scal[0] += weight * relu(thr - mean_i H_i),
+ * dz (nullable) += its gradient; ent fp32[4] in = {0, +inf, 0, 0}, out = {sum H, min H, max H, -}. */
+int dcc_entropy_reg(const float* z, float* dz, int B, int M, float weight, float thr, float* ent, float* scal,
+                    void* stream);
+/* Symmetric multi-positive InfoNCE on logits z [N,M] with weights w (utils/loss/multi_positive_infonce.py:9-110):
+ * wsum / msum / imp = row and column sums of the clamped weights, of the mask, of the importance base (imp nullable);
+ * ws = zeroed fp32[2(N+M)]; scal[0] += loss; dz (nullable) = dL/dz. */
+int dcc_mp_infonce(const float* z, const float* w, const float* lse_r, const float* lse_c, const float* wsum_r,
+                   const float* wsum_c, const float* msum_r, const float* msum_c, const float* imp_r,
+                   const float* imp_c, float* ws, float* dz, int N, int M, int mean, float imp_eps, float* scal,
+                   void* stream);
 /* out = targets * weights unless every weight is zero, then targets (runner.py:1276-1278); nz: zeroed fp32[1]. */
 int dcc_mp_pos_weights(const float* targets, const float* weights, float* out, int64_t n, float* nz, void* stream);
 

@@ -198,8 +198,85 @@ def retrieval():
     np.savez_compressed(os.path.join(OUT, "retrieval.npz"), **out)
 
 
+def loss_zoo():
+    """Remaining loss zoo: auto-balance / entropy-regularised contrastive.SigLIPLoss,
+    siglip_pairwise.SiglipPairwiseFeatureLoss, multi_positive_infonce.MultiPositiveInfoNCELoss, and the runner's
+    abnormal-margin column offset (runner.py:1265-1274) through WeightedSigLIPLoss — on the [8 x 13] multi-positive case."""
+    import torch.nn.functional as F
+    from utils.loss import contrastive as C
+    from utils.loss import siglip_pairwise as SP
+    from utils.loss.multi_positive_infonce import MultiPositiveInfoNCELoss
+    from utils.loss.weighted_siglip import WeightedSigLIPLoss
+
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    v = torch.randn(8, 512, generator=g).requires_grad_(True)
+    t = torch.randn(13, 512, generator=g).requires_grad_(True)
+    lt = torch.log(torch.tensor(0.07)).requires_grad_(True)
+    mask = torch.zeros(8, 13)
+    for i in range(8):
+        for j in torch.randperm(13, generator=g)[: 1 + i % 3].tolist():
+            mask[i, j] = 1.0
+    w = mask * (1.0 + 9.0 * torch.rand(8, 13, generator=g))
+    out.update(v=np_(v), t=np_(t), mask=np_(mask), w=np_(w))
+
+    def run(name, fn, bias_of=None):
+        for x in (v, t, lt):
+            x.grad = None
+        loss = fn()
+        loss.backward()
+        out[f"{name}_loss"], out[f"{name}_dv"], out[f"{name}_dt"], out[f"{name}_dlt"] = np_(loss), np_(v.grad), np_(t.grad), np_(lt.grad)
+        if bias_of is not None:
+            out[f"{name}_dbias"] = np_(bias_of.bias.grad)
+
+    m = C.SigLIPLoss(auto_balance=True)
+    run("bce_auto", lambda: m(v, t, lt, pos_mask=mask, pos_weights=w), m)
+    m2 = C.SigLIPLoss(entropy_regularization=True, entropy_weight=0.1, min_entropy_threshold=3.0)  # ln 13 < 3: always active
+    run("bce_ent", lambda: m2(v, t, lt, pos_mask=mask, pos_weights=w), m2)
+    d = m2.get_entropy_diagnostics()
+    out["bce_ent_diag"] = np.array([d[k] for k in ("entropy_mean", "entropy_min", "entropy_max", "entropy_normalized",
+                                                    "entropy_deficit", "bce_loss", "entropy_loss")])
+    m3 = C.SigLIPLoss(entropy_regularization=True, entropy_weight=0.1, min_entropy_threshold=0.01)  # inactive branch
+    run("bce_ent_off", lambda: m3(v, t, lt, pos_mask=mask, pos_weights=w), m3)
+    run("spf", lambda: SP.SiglipPairwiseFeatureLoss()(v, t, lt, mask, w))
+    run("spf_noweights", lambda: SP.SiglipPairwiseFeatureLoss(use_positive_weights=False, positive_weight=2.0, negative_weight=0.5)(v, t, lt, mask, w))
+    run("spf_auto", lambda: SP.SiglipPairwiseFeatureLoss(auto_positive_weight=True)(v, t, lt, mask, w))
+    run("spf_ent", lambda: SP.SiglipPairwiseFeatureLoss(entropy_regularization=True, entropy_weight=0.2, min_entropy_threshold=3.0)(v, t, lt, mask, w))
+    # runner inline branch with the abnormal margin on some text columns
+    abn = torch.zeros(13)
+    abn[[1, 4, 9]] = 1.0
+
+    def margin_loss():
+        sim = F.normalize(v, dim=1) @ F.normalize(t, dim=1).t()
+        logits = sim * torch.sigmoid(sim) / torch.exp(lt.float()) + abn.unsqueeze(0) * 0.35
+        return WeightedSigLIPLoss()(logits=logits, positive_weights=mask * w)
+
+    run("margin_wce", margin_loss)
+    out["abn"] = np_(abn)
+    # multi-positive InfoNCE on logits; row 5 and column 2 lose their positives
+    mask2 = mask.clone()
+    mask2[5] = 0.0
+    mask2[:, 2] = 0.0
+    w2 = 1.0 + 9.0 * torch.rand(8, 13, generator=g)
+    logits0 = (F.normalize(v.detach(), dim=1) @ F.normalize(t.detach(), dim=1).t() / 0.07)
+    out.update(nce_logits=np_(logits0), nce_mask=np_(mask2), nce_w=np_(w2))
+    for name, kw, pw in (("nce_mean", {}, w2), ("nce_sum", {"reduction": "sum"}, w2), ("nce_nopw", {}, None),
+                         ("nce_imp", {"use_importance_weighting": True}, w2),
+                         ("nce_imp_sum", {"use_importance_weighting": True, "reduction": "sum"}, None)):
+        z = logits0.clone().requires_grad_(True)
+        loss = MultiPositiveInfoNCELoss(**kw)(z, mask2, pw)
+        loss.backward()
+        out[f"{name}_loss"], out[f"{name}_dz"] = np_(loss), np_(z.grad)
+    z = logits0.clone().requires_grad_(True)
+    out["nce_empty_loss"] = np_(MultiPositiveInfoNCELoss()(z, torch.zeros_like(mask2), None))
+    np.savez_compressed(os.path.join(OUT, "loss_zoo.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    for fn in (losses, rope, pools, bert, retrieval):
+    only = sys.argv[1:]
+    for fn in (losses, rope, pools, bert, retrieval, loss_zoo):
+        if only and fn.__name__ not in only:
+            continue
         fn()
         print("wrote", fn.__name__)

@@ -185,3 +185,70 @@ def test_upstream_gradient_scaling_and_shape_errors():
         ContrastiveLoss()(v[:5], t, lt)
     with pytest.raises(ValueError):
         WeightedSigLIPLoss()(v, t, lt, torch.ones(3, 3, device="cuda"))
+
+
+def _z():
+    return np.load(os.path.join(G, "loss_zoo.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("name", ["bce_auto", "bce_ent", "bce_ent_off", "spf", "spf_noweights", "spf_auto", "spf_ent", "margin_wce"])
+def test_loss_zoo_matches_reference_goldens(name):
+    """N4 loss zoo on the HIP path vs tests/golden/loss_zoo.npz (generated from the reference's own modules): auto-balance,
+    entropy regulariser (active / inactive), SiglipPairwiseFeatureLoss variants, abnormal-margin column offset."""
+    from deepcoro_clip_amd import losses as Ls
+
+    g = _z()
+    v, t, lt = _dev(g["v"], True), _dev(g["t"], True), _lt()
+    mask, w = _dev(g["mask"]), _dev(g["w"])
+    mod = None
+    if name == "bce_auto":
+        mod = Ls.SigLIPLoss(auto_balance=True).cuda()
+        loss = mod(v, t, lt, pos_mask=mask, pos_weights=w)
+    elif name in ("bce_ent", "bce_ent_off"):
+        mod = Ls.SigLIPLoss(entropy_regularization=True, entropy_weight=0.1, min_entropy_threshold=3.0 if name == "bce_ent" else 0.01).cuda()
+        loss = mod(v, t, lt, pos_mask=mask, pos_weights=w)
+    elif name == "spf":
+        loss = Ls.SiglipPairwiseFeatureLoss()(v, t, lt, mask, w)
+    elif name == "spf_noweights":
+        loss = Ls.SiglipPairwiseFeatureLoss(use_positive_weights=False, positive_weight=2.0, negative_weight=0.5)(v, t, lt, mask, w)
+    elif name == "spf_auto":
+        loss = Ls.SiglipPairwiseFeatureLoss(auto_positive_weight=True)(v, t, lt, mask, w)
+    elif name == "spf_ent":
+        m2 = Ls.SiglipPairwiseFeatureLoss(entropy_regularization=True, entropy_weight=0.2, min_entropy_threshold=3.0)
+        loss = m2(v, t, lt, mask, w)
+    else:
+        loss = Ls.WeightedSigLIPLoss()(v, t, lt, _dev(g["mask"] * g["w"]), col_margin=_dev(g["abn"]) * 0.35)
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{name}_loss"])) < 1e-4 * max(1.0, abs(float(g[f"{name}_loss"]))), (loss.item(), float(g[f"{name}_loss"]))
+    assert _relf(v.grad, g[f"{name}_dv"]) < 2e-4 and _relf(t.grad, g[f"{name}_dt"]) < 2e-4, (_relf(v.grad, g[f"{name}_dv"]), _relf(t.grad, g[f"{name}_dt"]))
+    assert abs(lt.grad.item() - float(g[f"{name}_dlt"])) < 2e-4 * max(1e-3, abs(float(g[f"{name}_dlt"])))
+    if mod is not None:
+        assert abs(mod.bias.grad.item() - float(g[f"{name}_dbias"])) < 2e-4 * max(1e-6, abs(float(g[f"{name}_dbias"])))
+    if name == "bce_ent":
+        d = mod.get_entropy_diagnostics()
+        ref = g["bce_ent_diag"]
+        for k, r in zip(("entropy_mean", "entropy_min", "entropy_max", "entropy_normalized", "entropy_deficit", "bce_loss", "entropy_loss"), ref):
+            assert abs(d[k] - float(r)) < 1e-4 * max(1.0, abs(float(r))), (k, d[k], float(r))
+
+
+@pytest.mark.parametrize("name,kw,use_w", [("nce_mean", {}, True), ("nce_sum", {"reduction": "sum"}, True), ("nce_nopw", {}, False),
+                                           ("nce_imp", {"use_importance_weighting": True}, True),
+                                           ("nce_imp_sum", {"use_importance_weighting": True, "reduction": "sum"}, False)])
+def test_multi_positive_infonce_matches_reference_goldens(name, kw, use_w):
+    from deepcoro_clip_amd.losses import MultiPositiveInfoNCELoss
+
+    g = _z()
+    z = _dev(g["nce_logits"], True)
+    loss = MultiPositiveInfoNCELoss(**kw)(z, _dev(g["nce_mask"]), _dev(g["nce_w"]) if use_w else None)
+    (loss * 2.0).backward()
+    assert abs(loss.item() - float(g[f"{name}_loss"])) < 1e-4 * max(1.0, abs(float(g[f"{name}_loss"])))
+    assert _relf(z.grad, 2.0 * g[f"{name}_dz"]) < 2e-4
+    if name == "nce_mean":  # nothing selected anywhere: zero loss, zero gradient
+        z2 = _dev(g["nce_logits"], True)
+        l0 = MultiPositiveInfoNCELoss()(z2, torch.zeros(8, 13, device="cuda"))
+        l0.backward()
+        assert l0.item() == 0.0 and float(z2.grad.abs().max()) == 0.0
+        with pytest.raises(ValueError):
+            MultiPositiveInfoNCELoss()(z2, torch.zeros(8, 12, device="cuda"))
+        with pytest.raises(ValueError):
+            MultiPositiveInfoNCELoss(reduction="max")

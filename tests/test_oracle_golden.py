@@ -181,3 +181,51 @@ def test_mvit_structural_known_answers():
     with torch.no_grad():
         y = small.forward_features(torch.randn(1, 3, 4, 112, 112))
     assert y.shape == (1, 33, 768)  # BASELINE config 1: L = 2*4*4 + 1
+
+
+def test_loss_zoo_oracle_matches_reference():
+    """tests/golden/loss_zoo.npz (generated from utils/loss/contrastive.py, siglip_pairwise.py, multi_positive_infonce.py,
+    weighted_siglip.py): auto-balance, entropy regulariser (active and inactive), SiglipPairwiseFeatureLoss variants, the
+    abnormal-margin column offset, multi-positive InfoNCE reductions."""
+    import os
+
+    import numpy as np
+    from oracle import losses as OL
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_zoo.npz"))
+    T = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    mask, w = T("mask"), T("w")
+    lt0 = torch.log(torch.tensor(0.07))
+
+    def check(name, fn, with_bias=False):
+        v, t = T("v").clone().requires_grad_(True), T("t").clone().requires_grad_(True)
+        lt = lt0.clone().requires_grad_(True)
+        bias = torch.tensor(-10.0, requires_grad=True) if with_bias else torch.tensor(0.0)
+        loss = fn(v, t, lt, bias)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"{name}_loss"])) < 1e-5 * max(1.0, abs(float(g[f"{name}_loss"]))), name
+        for got, key in ((v.grad, "dv"), (t.grad, "dt")):
+            ref = T(f"{name}_{key}")
+            assert (got - ref).norm() <= 2e-4 * ref.norm().clamp_min(1e-12), (name, key)
+        assert abs(lt.grad.item() - float(g[f"{name}_dlt"])) < 2e-4 * max(1e-3, abs(float(g[f"{name}_dlt"]))), name
+        if with_bias:
+            assert abs(bias.grad.item() - float(g[f"{name}_dbias"])) < 2e-4 * max(1e-6, abs(float(g[f"{name}_dbias"]))), name
+
+    check("bce_auto", lambda v, t, lt, b: OL.siglip_bce_loss(v, t, lt, b, mask, w, auto_balance=True), True)
+    check("bce_ent", lambda v, t, lt, b: OL.siglip_bce_loss(v, t, lt, b, mask, w, entropy_weight=0.1, min_entropy_threshold=3.0), True)
+    check("bce_ent_off", lambda v, t, lt, b: OL.siglip_bce_loss(v, t, lt, b, mask, w, entropy_weight=0.1, min_entropy_threshold=0.01), True)
+    pw = dict(clamp_temp=False, pos_thr=0.0)
+    check("spf", lambda v, t, lt, b: OL.siglip_bce_loss(v, t, lt, b, mask, w, **pw))
+    check("spf_noweights", lambda v, t, lt, b: OL.siglip_bce_loss(v, t, lt, b, mask, None, positive_weight=2.0, negative_weight=0.5, **pw))
+    check("spf_auto", lambda v, t, lt, b: OL.siglip_bce_loss(v, t, lt, b, mask, w, auto_balance=True, **pw))
+    check("spf_ent", lambda v, t, lt, b: OL.siglip_bce_loss(v, t, lt, b, mask, w, entropy_weight=0.2, min_entropy_threshold=3.0, **pw))
+    check("margin_wce", lambda v, t, lt, b: OL.runner_multipositive_loss(v, t, lt, mask, w, weighted=True, col_margin=T("abn") * 0.35)[0])
+    for name, kw, use_w in (("nce_mean", {}, True), ("nce_sum", {"reduction": "sum"}, True), ("nce_nopw", {}, False),
+                            ("nce_imp", {"use_importance_weighting": True}, True),
+                            ("nce_imp_sum", {"use_importance_weighting": True, "reduction": "sum"}, False)):
+        z = T("nce_logits").clone().requires_grad_(True)
+        loss = OL.multi_positive_infonce(z, T("nce_mask"), T("nce_w") if use_w else None, **kw)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"{name}_loss"])) < 1e-5 * max(1.0, abs(float(g[f"{name}_loss"]))), name
+        assert (z.grad - T(f"{name}_dz")).norm() <= 1e-4 * T(f"{name}_dz").norm(), name
+    assert OL.multi_positive_infonce(T("nce_logits"), torch.zeros(8, 13)).item() == float(g["nce_empty_loss"]) == 0.0
