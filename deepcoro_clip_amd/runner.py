@@ -128,6 +128,7 @@ class VideoContrastiveLearningRunner:
         self._wgrad_side = os.environ.get("DCC_WGRAD_STREAM", "0") == "1"  # measured: +5 ms of host launch time > what it hides
         self._graph_stream: torch.cuda.Stream | None = None
         self._cache_check = os.environ.get("DCC_CACHE_CHECK", "0") == "1"
+        self._arena = Fn.ZeroArena()  # this runner's per-step gradient arena (installed as functional.ARENA by _zero_grad)
 
     # ------------------------------------------------------------------------------------------ helpers
     def _scheduler_is_per_iteration(self) -> bool:
@@ -148,6 +149,7 @@ class VideoContrastiveLearningRunner:
             dev = self.log_temp.device if self.log_temp is not None else torch.device("cuda")
             hint = sum(p.numel() for g in self.optimizer.param_groups for p in g["params"]) + (1 << 20)
             self._rehome_orphan_grads()
+            Fn.ARENA = self._arena  # two runners in one process must not hand out each other's gradient memory
             Fn.ARENA.begin(dev, hint)
 
     def _rehome_orphan_grads(self):
@@ -155,7 +157,7 @@ class VideoContrastiveLearningRunner:
         own bias — SURVEY §9.11) keep accumulating across steps.  When such a `.grad` is a slice of the per-step zero arena
         it must leave the arena before `begin()` re-zeroes and re-issues that memory: clone it out once; from then on
         autograd accumulates into the private clone."""
-        buf = Fn.ARENA.buf
+        buf = self._arena.buf
         if buf is None:
             return
         if getattr(self, "_orphans", None) is None:
