@@ -7,11 +7,13 @@ current HIP stream; nothing in the signatures is a torch type.
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 
 import torch
 
-LIB_PATH = Path(__file__).resolve().parent / "libdcc_hip.so"
+# DCC_LIB: alternative build of the same library (kernel A/B runs from tools/, see build.build_variant)
+LIB_PATH = Path(os.environ.get("DCC_LIB") or (Path(__file__).resolve().parent / "libdcc_hip.so"))
 
 DCC_F32, DCC_BF16 = 0, 1
 _ERR = {-1: "DCC_ERR_ARG", -2: "DCC_ERR_LAUNCH", -3: "DCC_ERR_UNSUPPORTED"}

@@ -40,10 +40,11 @@ FILE_FLAGS = {
 }
 
 
-def _compile(src: Path, headers: list[Path], force: bool) -> Path:
-    obj = OBJ_DIR / (src.stem + ".o")
+def _compile(src: Path, headers: list[Path], force: bool, obj_dir: Path = None, extra: dict | None = None) -> Path:
+    obj = (obj_dir or OBJ_DIR) / (src.stem + ".o")
     if force or _needs(obj, [src] + headers):
-        cmd = [HIPCC, *CFLAGS, *FILE_FLAGS.get(src.name, []), "-I", str(CSRC), "-c", str(src), "-o", str(obj)]
+        cmd = [HIPCC, *CFLAGS, *FILE_FLAGS.get(src.name, []), *(extra or {}).get(src.name, []), "-I", str(CSRC), "-c", str(src),
+               "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
@@ -69,5 +70,33 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     return LIB_PATH
 
 
+def build_variant(name: str, file_flags: dict[str, list[str]]) -> Path:
+    """A second copy of the library with extra per-file compiler flags (e.g. {"gemm_ring.hip": ["-DRING_X=1"]}) as
+    `libdcc_hip_<name>.so`, for A/B runs of one kernel from tools/ (select it with DCC_LIB=<path>).  Files without extra
+    flags reuse the main build's objects."""
+    build(verbose=False)
+    vdir = CSRC / f"build_{name}"
+    vdir.mkdir(parents=True, exist_ok=True)
+    headers = sorted(CSRC.glob("*.h"))
+    objs = []
+    for src in _sources():
+        if src.name in file_flags:
+            objs.append(_compile(src, headers, True, vdir, file_flags))
+        else:
+            objs.append(OBJ_DIR / (src.stem + ".o"))
+    lib = vdir / f"libdcc_hip_{name}.so"  # outside the package directory proper: not picked up as a module
+    r = subprocess.run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(lib), *map(str, objs)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if len(sys.argv) >= 4 and sys.argv[1] == "--variant":  # build.py --variant NAME file.hip=-DFOO=1,-mllvm,-x ...
+        flags = {}
+        for spec in sys.argv[3:]:
+            f, v = spec.split("=", 1)
+            flags[f] = [x for x in v.split(",") if x]
+        print(build_variant(sys.argv[2], flags))
+    else:
+        build(force="--force" in sys.argv)

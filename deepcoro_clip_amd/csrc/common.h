@@ -112,6 +112,30 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * 0.39894228040143267794f * e;
 }
 
+// GELU for bf16 OUTPUTS (the ring GEMM's epilogue crew, where the exp/rcp/FMA count of the erf form sets the pace of the
+// whole kernel): x * sigmoid(x (a + b x^2)) with (a, b) fitted to x Phi(x), |error| < 2.8e-4 absolute everywhere — an
+// order of magnitude below the bf16 rounding of the value it replaces (2^-9 relative) — in 6 VALU + 2 transcendental
+// instructions instead of ~17 + 2.  dgelu_bf16 is the exact derivative of gelu_bf16, so forward and backward stay
+// consistent.  fp32 compute keeps the erf form above.
+__device__ __forceinline__ float gelu_bf16(float x) {
+  const float u = x * (1.60031417f + 0.06940178f * x * x);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u));
+}
+__device__ __forceinline__ float dgelu_bf16(float x) {
+  const float x2 = x * x;
+  const float u = x * (1.60031417f + 0.06940178f * x2);
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u));
+  return s * (1.0f + x * (1.60031417f + 0.20820534f * x2) * (1.0f - s));
+}
+
+// element-type dispatch: bf16 tensors take the cheap pair everywhere (one definition of GELU per compute dtype)
+template <typename T> __device__ __forceinline__ float gelu_for(float x) {
+  if constexpr (sizeof(T) == 2) return gelu_bf16(x); else return gelu_f(x);
+}
+template <typename T> __device__ __forceinline__ float dgelu_for(float x) {
+  if constexpr (sizeof(T) == 2) return dgelu_bf16(x); else return dgelu_f(x);
+}
+
 // Counter-based keep masks (dropout): splitmix64 finaliser of (seed, element index); a mask is regenerated from the
 // same (seed, index) wherever it is needed again (backward) instead of being stored.
 __device__ __forceinline__ uint32_t hash32(uint64_t k) {

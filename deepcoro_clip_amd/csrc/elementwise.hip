@@ -106,7 +106,7 @@ __global__ void u8_normalize_kernel(const uint8_t* __restrict__ src, float* __re
 template <typename T>
 __global__ void dgelu_mul_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = from_f32<T>(to_f32(dy[i]) * dgelu_f(to_f32(pre[i])));
+    out[i] = from_f32<T>(to_f32(dy[i]) * dgelu_for<T>(to_f32(pre[i])));
 }
 
 // out[n] += sum_m x[m*ldx + n]
@@ -336,9 +336,94 @@ __global__ void scale_by_dev_kernel(float* __restrict__ x, int64_t n, const floa
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= c;
 }
 
+// ---- fp8 quantisation (per-tensor scale) for the fp8 GEMMs of BASELINE configs[4] ------------------------------------
+// amax[0] = max(amax[0], max |x|): float bit patterns of non-negative values order like unsigned integers
+template <typename T>
+__global__ void absmax_kernel(const T* __restrict__ x, int64_t rows, int64_t cols, int64_t ldx, float* __restrict__ amax) {
+  float m = 0.0f;
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(to_f32(x[(i / cols) * ldx + (i % cols)])));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));
+}
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d, float lim, int bf8) {
+  a = fminf(fmaxf(a, -lim), lim); b = fminf(fmaxf(b, -lim), lim); c = fminf(fmaxf(c, -lim), lim); d = fminf(fmaxf(d, -lim), lim);
+  int v = 0;
+  if (bf8) { v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, v, false); v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true); }
+  else { v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false); v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true); }
+  return (unsigned)v;
+}
+// q = fp8(x * FMAX / amax), scale_out[0] = amax / FMAX (the dequantisation multiplier); cols % 4 == 0
+template <typename T>
+__global__ void fp8_quant_kernel(const T* __restrict__ x, int64_t rows, int64_t cols, int64_t ldx, const float* __restrict__ amax,
+                                 unsigned* __restrict__ out, int64_t ldo4, float fmax_, int bf8, float* __restrict__ scale_out) {
+  const float am = *amax;
+  const float mul = am > 0.0f ? fmax_ / am : 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = am > 0.0f ? am / fmax_ : 1.0f;
+  const int64_t c4 = cols / 4, n4 = rows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4, c = (i % c4) * 4;
+    const T* p = x + r * ldx + c;
+    out[r * ldo4 + c / 4] = pack4_fp8(to_f32(p[0]) * mul, to_f32(p[1]) * mul, to_f32(p[2]) * mul, to_f32(p[3]) * mul, fmax_, bf8);
+  }
+}
+// transposed output: out8[c][r] = fp8(x[r][c] * mul): 32 x 32 tiles through LDS (weights only: small)
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_quant_t_kernel(const T* __restrict__ x, int rows, int cols, int64_t ldx,
+                                                          const float* __restrict__ amax, uint8_t* __restrict__ out, int64_t ldo,
+                                                          float fmax_, int bf8, float* __restrict__ scale_out) {
+  __shared__ float tile[32][33];
+  const float am = *amax;
+  const float mul = am > 0.0f ? fmax_ / am : 1.0f;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *scale_out = am > 0.0f ? am / fmax_ : 1.0f;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int r = r0 + i / 32, c = c0 + i % 32;
+    tile[i / 32][i % 32] = (r < rows && c < cols) ? to_f32(x[(int64_t)r * ldx + c]) * mul : 0.0f;
+  }
+  __syncthreads();
+  // thread = (output row c, 4 consecutive output columns r): one packed store
+  const int oc = threadIdx.x / 8, og = threadIdx.x % 8;
+  const int c = c0 + oc, r = r0 + 4 * og;
+  if (c < cols && r < rows) {  // rows % 4 == 0 is required by the caller
+    const unsigned v = pack4_fp8(tile[4 * og][oc], tile[4 * og + 1][oc], tile[4 * og + 2][oc], tile[4 * og + 3][oc], fmax_, bf8);
+    *reinterpret_cast<unsigned*>(out + (int64_t)c * ldo + r) = v;
+  }
+}
+
 }  // namespace
 
 #define ST (hipStream_t) stream
+
+extern "C" int dcc_absmax(const void* x, int64_t rows, int64_t cols, int64_t ldx, int dtype, float* amax, void* stream) {
+  if (!x || !amax || rows <= 0 || cols <= 0) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(rows * cols, 8));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((absmax_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, rows, cols, ldx, amax);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((absmax_kernel<float>), g, dim3(256), 0, ST, (const float*)x, rows, cols, ldx, amax);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+// fmt: 0 = e4m3 (max 448), 1 = e5m2 (max 57344).  transpose != 0 writes out8[c][r] (ldo = row pitch of the output in bytes).
+extern "C" int dcc_fp8_quantize(const void* x, int64_t rows, int64_t cols, int64_t ldx, int dtype, const float* amax, void* out8,
+                                int64_t ldo, int transpose, int fmt, float* scale_out, void* stream) {
+  if (!x || !amax || !out8 || !scale_out || rows <= 0 || cols <= 0 || (fmt != 0 && fmt != 1)) return DCC_ERR_ARG;
+  const float fmax_ = fmt == 0 ? 448.0f : 57344.0f;
+  if (transpose) {
+    if ((rows % 4) || (ldo % 4) || ((uintptr_t)out8 & 3) || rows > 0x7fffffff || cols > 0x7fffffff) return DCC_ERR_UNSUPPORTED;
+    dim3 g((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    if (dtype == DCC_BF16) hipLaunchKernelGGL((fp8_quant_t_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, (int)rows, (int)cols, ldx, amax, (uint8_t*)out8, ldo, fmax_, fmt, scale_out);
+    else if (dtype == DCC_F32) hipLaunchKernelGGL((fp8_quant_t_kernel<float>), g, dim3(256), 0, ST, (const float*)x, (int)rows, (int)cols, ldx, amax, (uint8_t*)out8, ldo, fmax_, fmt, scale_out);
+    else return DCC_ERR_UNSUPPORTED;
+    return dcc_check_launch();
+  }
+  if ((cols % 4) || (ldo % 4) || ((uintptr_t)out8 & 3)) return DCC_ERR_UNSUPPORTED;
+  dim3 g(gs_blocks(rows * cols / 4, 4));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((fp8_quant_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, rows, cols, ldx, amax, (unsigned*)out8, ldo / 4, fmax_, fmt, scale_out);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((fp8_quant_kernel<float>), g, dim3(256), 0, ST, (const float*)x, rows, cols, ldx, amax, (unsigned*)out8, ldo / 4, fmax_, fmt, scale_out);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
 
 extern "C" int dcc_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream) {
   if (!src || !dst || n <= 0) return DCC_ERR_ARG;

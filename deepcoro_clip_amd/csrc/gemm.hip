@@ -361,18 +361,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
       }
       if (p.flags & GEMM_GELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        for (int e = 0; e < 8; ++e) v[e] = gelu_for<TC>(v[e]);
       }
       if (p.flags & GEMM_DGELU) {
         const T* ap = reinterpret_cast<const T*>(p.aux) + (int64_t)row * p.ldaux + col;
         if (full && sizeof(T) == 2) {
           const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)a[e]);
+          for (int e = 0; e < 8; ++e) v[e] *= dgelu_for<T>((float)a[e]);
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
-            if (col + e < p.N) v[e] *= dgelu_f(to_f32(ap[e]));
+            if (col + e < p.N) v[e] *= dgelu_for<T>(to_f32(ap[e]));
         }
       }
       if (p.flags & GEMM_RESID) {
@@ -545,6 +545,20 @@ int launch_skinny(const GemmParams& p, int b_km, hipStream_t st) {
 
 }  // namespace
 
+// fp8 x fp8 -> bf16: C[m][n] = alpha * sa * sb * sum_k A8(m,k) B8(n,k) (+ bias, GELU / GELU' / residual epilogues as
+// dcc_gemm); both operands k-contiguous bytes.  See include/dcc.h.
+extern "C" int dcc_gemm_fp8(const void* A8, const void* B8, void* C, const float* bias, const void* R, void* aux,
+                            const float* scale_a, const float* scale_b, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr,
+                            int64_t ldaux, int M, int N, int K, float alpha, int flags, int fmt_a, int fmt_b, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A8 || !B8 || !C) return DCC_ERR_ARG;
+  if ((flags & GEMM_BIAS) && !bias) return DCC_ERR_ARG;
+  if ((flags & GEMM_RESID) && !R) return DCC_ERR_ARG;
+  if ((flags & (GEMM_SAVE_PRE | GEMM_DGELU)) && !aux) return DCC_ERR_ARG;
+  if ((fmt_a | fmt_b) & ~1) return DCC_ERR_ARG;
+  GemmParams p{A8, B8, C, bias, R, aux, nullptr, lda, ldb, ldc, ldr, ldaux, 0, 0, 0, M, N, K, 1, 1, alpha, flags & 0xff, scale_a, scale_b, fmt_a, fmt_b};
+  return dcc_gemm_ring_launch_fp8(p, (hipStream_t)stream);
+}
+
 // See include/dcc.h for the contract.
 extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias, const void* R, void* aux,
                         float* colsum, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldaux, int M, int N,
@@ -572,7 +586,7 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   if ((flags & GEMM_COLSUM_A) && (!colsum || !a_km || batch != 1)) return DCC_ERR_ARG;
   if (splitk > 1 && (flags & 0xff & ~(GEMM_BIAS | GEMM_ACCUM | GEMM_COLSUM_A))) return DCC_ERR_ARG;  // non-linear epilogues need the full sum
   if (!aligned && in_dtype != DCC_F32) return DCC_ERR_UNSUPPORTED;  // bf16 callers always meet the chunk rules
-  GemmParams p{A, B, C, bias, R, aux, colsum, lda, ldb, ldc, ldr, ldaux, sA, sB, sC, M, N, K, batch, splitk, alpha, (flags & 0xff) | (((flags >> 8) & 0xff) == 4 ? 0x1000 : 0) | (((flags >> 8) & 0xff) == 7 ? 0x2000 : 0)};
+  GemmParams p{A, B, C, bias, R, aux, colsum, lda, ldb, ldc, ldr, ldaux, sA, sB, sC, M, N, K, batch, splitk, alpha, (flags & 0xff) | (((flags >> 8) & 0xff) == 4 ? 0x1000 : 0) | (((flags >> 8) & 0xff) == 7 ? 0x2000 : 0), nullptr, nullptr, 0, 0};
   if ((int64_t)batch * splitk > 65535) return DCC_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == DCC_F32 && out_dtype == DCC_F32 && aligned && !a_km && M <= 32 && batch == 1 && splitk == 1 && K >= 64 &&

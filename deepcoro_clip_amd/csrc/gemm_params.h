@@ -25,8 +25,15 @@ struct GemmParams {
   int batch, splitk;
   float alpha;
   int flags;
+  // fp8 operands (gemm_ring.hip, F8 variant): per-tensor dequantisation scales on the device (alpha *= *scale_a * *scale_b)
+  // and the element formats of A / B (0 = e4m3, 1 = e5m2)
+  const float* scale_a;
+  const float* scale_b;
+  int fmt_a, fmt_b;
 };
 
 // Persistent ring kernel (gemm_ring.hip). Returns DCC_OK, or DCC_ERR_UNSUPPORTED when the shape/layout is outside
 // what it handles (the caller then runs the register-staged kernel).
 int dcc_gemm_ring_launch(const GemmParams& p, int a_km, int b_km, int out_dtype, hipStream_t stream);
+// fp8 x fp8 -> bf16 with the block-scaled MFMA (k-contiguous operands only)
+int dcc_gemm_ring_launch_fp8(const GemmParams& p, hipStream_t stream);

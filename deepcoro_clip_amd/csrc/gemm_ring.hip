@@ -336,12 +336,12 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
               }
               if (p.flags & GEMM_GELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = gelu_for<TC>(v[e]);
               }
               if (p.flags & GEMM_DGELU) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)a[e]);
+                for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf16((float)a[e]);
               }
               if (p.flags & GEMM_RESID) {
                 const TC* rp = R + (int64_t)row * p.ldr + col;
@@ -397,9 +397,16 @@ constexpr int MB_B = BMN * MB_PITCH;
 constexpr int NS2 = 3;
 constexpr int NT2 = 64 * 12;
 
-template <bool A_KM, bool B_KM>
+// F8: operands are fp8 bytes (k-contiguous only): a ring stage then holds 128 k per row instead of 64 — the same 128-byte
+// rows, pieces and swizzle — and the consumers run 8 block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales, the
+// per-tensor scales ride in alpha) instead of 16 bf16 MFMAs per K-step: half the K-steps per tile at the same step cost.
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+template <bool A_KM, bool B_KM, bool F8>
 __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo geo) {
   constexpr int NS = NS2, D = NS - 1, PPL = 4;
+  constexpr int ES = F8 ? 1 : 2;          // operand element size
+  constexpr int BKE = BK * 2 / ES;        // k elements per ring stage (128-byte rows)
+  static_assert(!F8 || (!A_KM && !B_KM), "fp8 operands are k-contiguous");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* mbox = smem + NS * STAGE_B;
 
@@ -435,9 +442,9 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
       const int g = w4 * PPL + j;
       kcA[j] = kcB[j] = 0;
       if (A_KM) { const int R = g * 4 + (lane >> 4), c = (lane & 15) ^ swz_km128(R); voffA[j] = (R * (int)p.lda + c * 8) * 2; }
-      else { const int R = g * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7); voffA[j] = (R * (int)p.lda + c * 8) * 2; kcA[j] = c * 8; }
+      else { const int R = g * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7); voffA[j] = R * (int)p.lda * ES + c * 16; kcA[j] = c * (16 / ES); }
       if (B_KM) { const int R = g * 4 + (lane >> 4), c = (lane & 15) ^ swz_km128(R); voffB[j] = (R * (int)p.ldb + c * 8) * 2; }
-      else { const int R = g * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7); voffB[j] = (R * (int)p.ldb + c * 8) * 2; kcB[j] = c * 8; }
+      else { const int R = g * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7); voffB[j] = R * (int)p.ldb * ES + c * 16; kcB[j] = c * (16 / ES); }
     }
     constexpr int OOB = 0x7fffff00;
     const int voffBias = ((w4 & 1) * 64 + lane) * 4;
@@ -445,17 +452,17 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
     const int kstrideB = B_KM ? BK * (int)p.ldb * 2 : BK * 2;
     auto bytes_left = [](bool km, int64_t ld, int rem, int K) -> unsigned {
       const int64_t elems = rem <= 0 ? 0 : (km ? (int64_t)(K - 1) * ld + rem : (int64_t)(rem - 1) * ld + K);
-      return (unsigned)(elems * 2);
+      return (unsigned)(elems * ES);
     };
     Item L = locate(item0);
     int l_kt = 0, issued = 0;
     __amdgpu_buffer_rsrc_t rsA, rsB, rsBias;
     auto bind = [&]() {
       if (L.idx >= geo.items) return;
-      const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (int64_t)L.bz * p.sA + (A_KM ? (int64_t)L.m0 : (int64_t)L.m0 * p.lda);
-      const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (int64_t)L.bz * p.sB + (B_KM ? (int64_t)L.n0 : (int64_t)L.n0 * p.ldb);
-      rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, bytes_left(A_KM, p.lda, p.M - L.m0, p.K), 0x00020000);
-      rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, bytes_left(B_KM, p.ldb, p.N - L.n0, p.K), 0x00020000);
+      const char* A = reinterpret_cast<const char*>(p.A) + ((int64_t)L.bz * p.sA + (A_KM ? (int64_t)L.m0 : (int64_t)L.m0 * p.lda)) * ES;
+      const char* B = reinterpret_cast<const char*>(p.B) + ((int64_t)L.bz * p.sB + (B_KM ? (int64_t)L.n0 : (int64_t)L.n0 * p.ldb)) * ES;
+      rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A), 0, bytes_left(A_KM, p.lda, p.M - L.m0, p.K), 0x00020000);
+      rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(B), 0, bytes_left(B_KM, p.ldb, p.N - L.n0, p.K), 0x00020000);
       const bool hb = (p.flags & GEMM_BIAS) != 0;
       rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb ? p.bias + L.n0 : (const float*)p.A), 0,
                                                  hb ? (unsigned)((p.N - L.n0) * 4) : 0u, 0x00020000);
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
     auto issue = [&]() {
       if (L.idx >= geo.items) return;
       char* st = smem + (issued % NS) * STAGE_B;
-      const int k0 = l_kt * BK;
+      const int k0 = l_kt * BKE;
       const int soA = l_kt * kstrideA, soB = l_kt * kstrideB;
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
@@ -514,6 +521,11 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
     f32x4 bias4[2][4];  // bias of this lane's columns, fetched during the tile's last K-step (its ring stage is recycled at the next barrier)
     bool pending = false;
     int kt = 0;
+    float alpha = p.alpha;
+    if constexpr (F8) {  // per-tensor dequantisation scales (device scalars written by the quantisation kernels)
+      if (p.scale_a) alpha *= *p.scale_a;
+      if (p.scale_b) alpha *= *p.scale_b;
+    }
     for (int q = 0; q < S + 2; ++q) {
       const unsigned long long tb0 = PROF_T();
       __builtin_amdgcn_s_barrier();
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
             for (int g4 = 0; g4 < 4; ++g4) {
               bf16x4 o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[i][j][4 * g4 + e] * p.alpha + bias4[j][g4][e]);
+              for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[i][j][4 * g4 + e] * alpha + bias4[j][g4][e]);
               *reinterpret_cast<bf16x4*>(rowp + 16 * g4) = o;
             }
           }
@@ -541,31 +553,75 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
       const unsigned long long tb2 = PROF_T();
       const char* sa = smem + (q % NS) * STAGE_B;
       const char* sb = sa + TILE_B;
-      bf16x8 fa[2][2], fb[2][2];
-      auto fetch = [&](int buf, int s) {
+      if constexpr (F8) {
+        // 32 k bytes per lane and MFMA: lane (r, h) of K-substep s holds k = 64 s + 32 h .. + 31 of its row = the two
+        // 16-byte chunks 4 s + 2 h, 4 s + 2 h + 1 of the 128-byte row (chunk ^ ((row >> 1) & 7) as stored by the loaders)
+        v8i32 ga[2][2], gb[2][2];
+        auto fetch8 = [&](int buf, int s) {
+          const int r = lane & 31, c0 = 4 * s + 2 * h;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[buf][i] = A_KM ? frag_km(sa, wr * 64 + 32 * i, s, lane) : frag_kc(sa, wr * 64 + 32 * i, s, lane);
+          for (int i = 0; i < 2; ++i) {
+            const int row = wr * 64 + 32 * i + r, sw = (row >> 1) & 7;
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(sa + row * 128 + ((c0 ^ sw) << 4));
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(sa + row * 128 + (((c0 + 1) ^ sw) << 4));
+            ga[buf][i] = v8i32{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+          }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[buf][j] = B_KM ? frag_km(sb, wc * 64 + 32 * j, s, lane) : frag_kc(sb, wc * 64 + 32 * j, s, lane);
-      };
-      fetch(0, 0);
+          for (int j = 0; j < 2; ++j) {
+            const int row = wc * 64 + 32 * j + r, sw = (row >> 1) & 7;
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(sb + row * 128 + ((c0 ^ sw) << 4));
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(sb + row * 128 + (((c0 + 1) ^ sw) << 4));
+            gb[buf][j] = v8i32{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+          }
+        };
+        fetch8(0, 0);
 #pragma unroll
-      for (int s = 0; s < BK / 16; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < BK / 16) fetch(cur ^ 1, s + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // swapped operands: the accumulator tile is C^T (rows = n on registers, columns = m on lanes)
-        if (s == 0 && kt == 0) {  // first MFMA of a tile starts from C = 0 (inline constant): no 64 v_mov to clear acc
+        for (int s = 0; s < 2; ++s) {
+          const int cur = s & 1;
+          if (s + 1 < 2) fetch8(cur ^ 1, s + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const bool first = (s == 0 && kt == 0);
           const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          constexpr int ONE = 0x7f7f7f7f;  // E8M0 block scale 2^0 in every byte
+          // swapped operands (C^T), formats from the launch: 0 = e4m3, 1 = e5m2 (uniform branch)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fb[cur][j], fa[cur][i], zero);
-        } else {
+            for (int j = 0; j < 2; ++j) {
+              const f32x16 cin = first ? zero : acc[i][j];
+              if (p.fmt_a == 0 && p.fmt_b == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(gb[cur][j], ga[cur][i], cin, 0, 0, 0, ONE, 0, ONE);
+              else if (p.fmt_a == 1 && p.fmt_b == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(gb[cur][j], ga[cur][i], cin, 0, 1, 0, ONE, 0, ONE);
+              else if (p.fmt_a == 0 && p.fmt_b == 1) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(gb[cur][j], ga[cur][i], cin, 1, 0, 0, ONE, 0, ONE);
+              else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(gb[cur][j], ga[cur][i], cin, 1, 1, 0, ONE, 0, ONE);
+            }
+        }
+      } else {
+        bf16x8 fa[2][2], fb[2][2];
+        auto fetch = [&](int buf, int s) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i) fa[buf][i] = A_KM ? frag_km(sa, wr * 64 + 32 * i, s, lane) : frag_kc(sa, wr * 64 + 32 * i, s, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fb[cur][j], fa[cur][i], acc[i][j]);
+          for (int j = 0; j < 2; ++j) fb[buf][j] = B_KM ? frag_km(sb, wc * 64 + 32 * j, s, lane) : frag_kc(sb, wc * 64 + 32 * j, s, lane);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+          const int cur = s & 1;
+          if (s + 1 < BK / 16) fetch(cur ^ 1, s + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          // swapped operands: the accumulator tile is C^T (rows = n on registers, columns = m on lanes)
+          if (s == 0 && kt == 0) {  // first MFMA of a tile starts from C = 0 (inline constant): no 64 v_mov to clear acc
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fb[cur][j], fa[cur][i], zero);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][j] = mma16(fb[cur][j], fa[cur][i], acc[i][j]);
+          }
         }
       }
       if (++kt == nk) {
@@ -633,13 +689,13 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
         if (p.flags & GEMM_SAVE_PRE) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col) = mv;
         if (p.flags & GEMM_GELU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = gelu_bf16(v[e]);
         }
         if (p.flags & GEMM_DGELU) {
           bf16x8 a = pre[k];
           if (p.flags & GEMM_RESID) a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)a[e]);
+          for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf16((float)a[e]);
         }
         if (p.flags & GEMM_RESID) {
 #pragma unroll
@@ -726,7 +782,7 @@ int dcc_gemm_ring_launch(const GemmParams& p, int a_km, int b_km, int out_dtype,
     constexpr int LDS2 = NS2 * STAGE_B + MB_B;
 #define RING2(AK, BK_)                                                                                              \
   do {                                                                                                              \
-    auto kern = gemm_ring2_kernel<AK, BK_>;                                                                         \
+    auto kern = gemm_ring2_kernel<AK, BK_, false>;                                                                  \
     static bool cfg = false;                                                                                        \
     if (!cfg) {                                                                                                     \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return DCC_ERR_LAUNCH; \
@@ -756,4 +812,38 @@ int dcc_gemm_ring_launch(const GemmParams& p, int a_km, int b_km, int out_dtype,
   if (out_dtype == DCC_F32) RING(float);
 #undef RING
   return DCC_ERR_UNSUPPORTED;
+}
+
+int dcc_gemm_ring_launch_fp8(const GemmParams& p, hipStream_t st) {
+  // byte operands, k-contiguous, 16-byte chunks; at least 2 K-steps of 128
+  if ((p.lda % 16) || (p.ldb % 16) || (p.sA % 16) || (p.sB % 16) || (p.K % 16) || (p.ldc % 8) || (p.N % 8) || (p.sC % 8)) return DCC_ERR_UNSUPPORTED;
+  if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15) || ((uintptr_t)p.C & 15)) return DCC_ERR_UNSUPPORTED;
+  if ((p.flags & GEMM_RESID) && ((p.ldr % 8) || ((uintptr_t)p.R & 15))) return DCC_ERR_UNSUPPORTED;
+  if ((p.flags & (GEMM_SAVE_PRE | GEMM_DGELU)) && ((p.ldaux % 8) || ((uintptr_t)p.aux & 15))) return DCC_ERR_UNSUPPORTED;
+  if ((p.flags & GEMM_BIAS) && ((uintptr_t)p.bias & 3)) return DCC_ERR_UNSUPPORTED;
+  if (p.splitk != 1 || (p.flags & (GEMM_ACCUM | GEMM_COLSUM_A))) return DCC_ERR_UNSUPPORTED;
+  if ((int64_t)p.M * p.lda >= (1LL << 31) || (int64_t)p.N * p.ldb >= (1LL << 31)) return DCC_ERR_UNSUPPORTED;
+  Geo geo;
+  const int tilesM = (p.M + BMN - 1) / BMN;
+  geo.tilesN = (p.N + BMN - 1) / BMN;
+  geo.tiles = tilesM * geo.tilesN;
+  const int64_t items = (int64_t)geo.tiles * p.batch;
+  if (items > 0x3fffffff) return DCC_ERR_UNSUPPORTED;
+  geo.items = (int)items;
+  geo.ksteps = (p.K + 2 * BK - 1) / (2 * BK);
+  geo.per = geo.ksteps;
+  if (geo.ksteps < 2) return DCC_ERR_UNSUPPORTED;
+  constexpr int LDS2 = NS2 * STAGE_B + MB_B;
+  auto kern = gemm_ring2_kernel<false, false, true>;
+  static bool cfg = false;
+  if (!cfg) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return DCC_ERR_LAUNCH;
+    cfg = true;
+  }
+  int G = num_cus() & ~7;
+  if (G < 8) G = 8;
+  const int need = (geo.items + 7) & ~7;
+  if (G > need) G = need;
+  hipLaunchKernelGGL(kern, dim3(G), dim3(NT2), LDS2, st, p, geo);
+  return dcc_check_launch();
 }

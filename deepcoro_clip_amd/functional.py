@@ -47,6 +47,50 @@ def wcast(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return t
 
 
+# ------------------------------------------------------------------------------ fp8 GEMM mode
+# BASELINE configs[4]: the towers' forward and data-gradient GEMMs in fp8 (block-scaled MFMA, per-tensor scales: e4m3 for
+# activations and weights, e5m2 for gradients), weight gradients stay bf16.  Switched on around the video trunk by
+# VideoEncoder(gemm_dtype="fp8"); shapes the fp8 kernel does not take (K <= 128, odd alignments) stay bf16.
+_FP8 = {"on": False}
+
+
+class fp8_gemms:
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        self.prev = _FP8["on"]
+        _FP8["on"] = bool(self.enabled)
+
+    def __exit__(self, *exc):
+        _FP8["on"] = self.prev
+        return False
+
+
+def _fp8_shape(rows: int, K_: int, N: int, dtype) -> bool:
+    return dtype == torch.bfloat16 and K_ % 16 == 0 and K_ > 128 and N % 8 == 0 and rows >= 128
+
+
+def _fp8_ok(rows: int, K_: int, N: int, dtype) -> bool:
+    return _FP8["on"] and _fp8_shape(rows, K_, N, dtype)
+
+
+def wquant(w: torch.Tensor, transpose: bool):
+    """fp8 (e4m3) copy of an fp32 weight [N, K] (or its transpose [K, N]) + its scale, cached on the parameter like the
+    bf16 shadows (valid for one (autograd version, optimizer epoch) pair)."""
+    owner = w._base if w._base is not None else w
+    cache = owner.__dict__.setdefault("_dcc_fp8", {})
+    key = (w.storage_offset(), tuple(w.shape), tuple(w.stride()), transpose)
+    stamp = (owner._version, _WEPOCH, owner.data_ptr())
+    hit = cache.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1], hit[2]
+    wd = w.detach()
+    q, sc = K.fp8_quantize(wd if wd.is_contiguous() else wd.contiguous(), 0, transpose)
+    cache[key] = (stamp, q, sc)
+    return q, sc
+
+
 def stacked_tables(tables, rows: int, width: int, dtype: torch.dtype) -> torch.Tensor:
     """The rel-pos tables stacked row-wise in the compute dtype, zero padded to `rows`.
 
@@ -196,7 +240,13 @@ class LinearFn(torch.autograd.Function):
         wc = wcast(weight, x.dtype)
         res2 = _c(residual).reshape(-1, N) if residual is not None else None
         pre = torch.empty((x2.shape[0], N), device=x.device, dtype=x.dtype) if gelu else None
-        y = K.gemm(x2, wc, bias=bias.detach() if bias is not None else None, gelu=gelu, save_pre=gelu, aux=pre, resid=res2)
+        ctx.fp8 = _fp8_ok(x2.shape[0], K_, N, x.dtype)
+        if ctx.fp8:
+            x8, sx = K.fp8_quantize(x2, 0)
+            w8, sw = wquant(weight, False)
+            y = K.gemm_fp8(x8, w8, sx, sw, bias=bias.detach() if bias is not None else None, gelu=gelu, save_pre=gelu, aux=pre, resid=res2)
+        else:
+            y = K.gemm(x2, wc, bias=bias.detach() if bias is not None else None, gelu=gelu, save_pre=gelu, aux=pre, resid=res2)
         ctx.save_for_backward(x2, wc, pre)
         ctx.params = (weight, bias)
         ctx.gelu = gelu
@@ -213,7 +263,12 @@ class LinearFn(torch.autograd.Function):
         g = K.dgelu_mul(dy2, pre) if ctx.gelu else dy2
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = K.gemm(g, wc, b_km=True).reshape(ctx.xshape)
+            if ctx.fp8 and _fp8_shape(g.shape[0], N, wc.shape[1], g.dtype):  # dX = dY W: gradients in e5m2, W^T in e4m3
+                g8, sg = K.fp8_quantize(g, 1)
+                wt8, swt = wquant(ctx.params[0], True)
+                dx = K.gemm_fp8(g8, wt8, sg, swt, fmt_a=1).reshape(ctx.xshape)
+            else:
+                dx = K.gemm(g, wc, b_km=True).reshape(ctx.xshape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_db:  # bias gradient rides in the weight-gradient GEMM (column sums of its k-major A operand)
@@ -242,9 +297,18 @@ class MlpFn(torch.autograd.Function):
         w1c, w2c = wcast(w1, x.dtype), wcast(w2, x.dtype)
         Hd, N = w1.shape[0], w2.shape[0]
         pre = torch.empty((x2.shape[0], Hd), device=x.device, dtype=x.dtype)
-        act = K.gemm(x2, w1c, bias=b1.detach(), gelu=True, save_pre=True, aux=pre)
         res2 = _c(residual).reshape(-1, N) if residual is not None else None
-        y = K.gemm(act, w2c, bias=b2.detach(), resid=res2)
+        ctx.fp8 = _fp8_ok(x2.shape[0], Kd, Hd, x.dtype) and _fp8_ok(x2.shape[0], Hd, N, x.dtype)
+        if ctx.fp8:
+            x8, sx = K.fp8_quantize(x2, 0)
+            w18, s1 = wquant(w1, False)
+            act = K.gemm_fp8(x8, w18, sx, s1, bias=b1.detach(), gelu=True, save_pre=True, aux=pre)
+            a8, sa = K.fp8_quantize(act, 0)
+            w28, s2 = wquant(w2, False)
+            y = K.gemm_fp8(a8, w28, sa, s2, bias=b2.detach(), resid=res2)
+        else:
+            act = K.gemm(x2, w1c, bias=b1.detach(), gelu=True, save_pre=True, aux=pre)
+            y = K.gemm(act, w2c, bias=b2.detach(), resid=res2)
         ctx.save_for_backward(x2, w1c, w2c, pre, act)
         ctx.params = (w1, b1, w2, b2)
         ctx.has_res = residual is not None
@@ -266,7 +330,13 @@ class MlpFn(torch.autograd.Function):
             dw2 = wgrad(dy2, act, db2, side=WGRAD_SIDE and grads_unset(*ctx.params[2:]), out=_grad_slots.take(ctx.params[2]))
         elif ctx.needs_input_grad[4]:
             db2 = K.colsum(dy2)
-        dpre = K.gemm(dy2, w2c, b_km=True, dgelu=True, aux=pre)
+        fp8 = ctx.fp8 and _fp8_shape(rows, N, Hd, dy2.dtype) and _fp8_shape(rows, Hd, x2.shape[1], dy2.dtype)
+        if fp8:
+            g8, sg = K.fp8_quantize(dy2, 1)
+            w2t8, s2t = wquant(ctx.params[2], True)
+            dpre = K.gemm_fp8(g8, w2t8, sg, s2t, fmt_a=1, dgelu=True, aux=pre)
+        else:
+            dpre = K.gemm(dy2, w2c, b_km=True, dgelu=True, aux=pre)
         if ctx.needs_input_grad[1]:
             db1 = (_grad_slots.take(ctx.params[1]) if ctx.needs_input_grad[2] else None)
             if db1 is None and ctx.needs_input_grad[2]:
@@ -275,7 +345,12 @@ class MlpFn(torch.autograd.Function):
         elif ctx.needs_input_grad[2]:
             db1 = K.colsum(dpre)
         if ctx.needs_input_grad[0]:
-            dx = K.gemm(dpre, w1c, b_km=True).reshape(ctx.xshape)
+            if fp8:
+                p8, sp = K.fp8_quantize(dpre, 1)
+                w1t8, s1t = wquant(ctx.params[0], True)
+                dx = K.gemm_fp8(p8, w1t8, sp, s1t, fmt_a=1).reshape(ctx.xshape)
+            else:
+                dx = K.gemm(dpre, w1c, b_km=True).reshape(ctx.xshape)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
 
 

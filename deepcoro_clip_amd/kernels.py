@@ -735,3 +735,53 @@ def clamp01(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(x)
     L.call("dcc_clamp", L.ptr(x), L.ptr(out), x.numel(), 0.0, 1.0, L.stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------ fp8
+def fp8_quantize(x2d: torch.Tensor, fmt: int = 0, transpose: bool = False):
+    """Per-tensor fp8 quantisation of a [rows, cols] view (unit inner stride): returns (uint8 tensor [rows, cols] or
+    [cols, rows], fp32[1] dequantisation scale = amax / FMAX).  fmt 0 = e4m3, 1 = e5m2."""
+    L.require_cuda(x2d)
+    assert x2d.dim() == 2 and x2d.stride(1) == 1
+    rows, cols = x2d.shape
+    amax = torch.zeros(1, device=x2d.device, dtype=torch.float32)
+    L.call("dcc_absmax", L.ptr(x2d), rows, cols, x2d.stride(0), L.dt(x2d), L.ptr(amax), L.stream())
+    out = torch.empty((cols, rows) if transpose else (rows, cols), device=x2d.device, dtype=torch.uint8)
+    scale = torch.empty(1, device=x2d.device, dtype=torch.float32)
+    L.call("dcc_fp8_quantize", L.ptr(x2d), rows, cols, x2d.stride(0), L.dt(x2d), L.ptr(amax), L.ptr(out), out.stride(0),
+           int(transpose), int(fmt), L.ptr(scale), L.stream())
+    return out, scale
+
+
+def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, *, fmt_a: int = 0, fmt_b: int = 0,
+             bias=None, resid=None, aux=None, gelu=False, save_pre=False, dgelu=False, alpha: float = 1.0,
+             out: torch.Tensor | None = None) -> torch.Tensor:
+    """C[m,n] = alpha * sa * sb * sum_k A8(m,k) B8(n,k) (+ epilogue) in bf16; a8 [M,K], b8 [N,K] uint8 (fp8 bytes)."""
+    L.require_cuda(a8, b8, sa, sb, bias, resid, aux, out)
+    assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and a8.dim() == 2 and b8.dim() == 2
+    assert a8.stride(1) == 1 and b8.stride(1) == 1 and a8.shape[1] == b8.shape[1]
+    M, K = a8.shape
+    N = b8.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a8.device, dtype=torch.bfloat16)
+    flags = 0
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+        flags |= GEMM_BIAS
+    if gelu:
+        flags |= GEMM_GELU
+    if save_pre:
+        assert aux is not None and aux.shape == (M, N) and aux.dtype == torch.bfloat16
+        flags |= GEMM_SAVE_PRE
+    if dgelu:
+        assert aux is not None and aux.shape == (M, N) and aux.dtype == torch.bfloat16
+        flags |= GEMM_DGELU
+    if resid is not None:
+        assert resid.shape == (M, N) and resid.dtype == torch.bfloat16 and resid.stride(1) == 1
+        flags |= GEMM_RESID
+    nbytes = (M * K + N * K) + M * N * 2 * (1 + int(resid is not None) + int(save_pre) + int(dgelu))
+    with _timed("gemm_fp8", 2.0 * M * N * K, lambda: f"M{M} N{N} K{K} f{flags}", nbytes):
+        L.call("dcc_gemm_fp8", L.ptr(a8), L.ptr(b8), L.ptr(out), L.ptr(bias), L.ptr(resid), L.ptr(aux), L.ptr(sa), L.ptr(sb),
+               a8.stride(0), b8.stride(0), out.stride(0), resid.stride(0) if resid is not None else 0,
+               aux.stride(0) if aux is not None else 0, M, N, K, float(alpha), flags, int(fmt_a), int(fmt_b), L.stream())
+    return out

@@ -74,6 +74,6 @@ def register_submodules(package_name: str = "deepcoro_clip_amd", recursive: bool
     """Import every submodule so that the @register decorators run (utils/registry.py:82-94)."""
     package = importlib.import_module(package_name)
     for _, name, is_pkg in pkgutil.walk_packages(package.__path__, package.__name__ + "."):
-        if name.endswith((".build", ".libdcc_hip")) or ".csrc" in name:
+        if name.endswith(".build") or ".libdcc_hip" in name or ".csrc" in name:
             continue  # the build script and the C-ABI shared object are not Python modules to register
         importlib.import_module(name)

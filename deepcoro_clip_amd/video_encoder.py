@@ -50,6 +50,7 @@ class VideoEncoder(nn.Module):
         spatial_size: tuple[int, int] = (224, 224),
         compute_dtype: torch.dtype = torch.bfloat16,
         stochastic_depth_prob: float = 0.2,
+        gemm_dtype: str = "bf16",
     ):
         super().__init__()
         self.backbone = backbone
@@ -65,6 +66,11 @@ class VideoEncoder(nn.Module):
         self.multi_video_cls_aggregation = multi_video_cls_aggregation
         self.encoder_path = encoder_path
         self.compute_dtype = compute_dtype
+        if gemm_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"gemm_dtype must be 'bf16' or 'fp8', got {gemm_dtype!r}")
+        if gemm_dtype == "fp8" and compute_dtype != torch.bfloat16:
+            raise ValueError("gemm_dtype='fp8' runs on bf16 activations: use compute_dtype=torch.bfloat16")
+        self.gemm_dtype = gemm_dtype  # "fp8": forward / data-gradient GEMMs of the trunk on the fp8 MFMA (BASELINE configs[4])
 
         if backbone in ("mvit", "mvit_rope"):
             if input_channels != 3:
@@ -164,7 +170,8 @@ class VideoEncoder(nn.Module):
 
     def _extract_backbone_features(self, x: torch.Tensor) -> torch.Tensor:
         """x: [B*N, T, H, W, C] fp32 channels-last -> [B*N, L, 768] (class token included, as in the reference)."""
-        return self.model.forward_features(x, self.compute_dtype)
+        with Fn.fp8_gemms(self.gemm_dtype == "fp8"):
+            return self.model.forward_features(x, self.compute_dtype)
 
     def _compute_feature_dict(self, x: torch.Tensor, compute_aggregated: bool) -> Dict[str, torch.Tensor]:
         if x.ndim == 5:

@@ -59,6 +59,20 @@ int dcc_gemm(const void* A, const void* B, void* C, const float* bias, const voi
              int64_t sA, int64_t sB, int64_t sC, int splitk, float alpha, int flags, int a_km, int b_km,
              int in_dtype, int out_dtype, void* stream);
 
+/* ---- fp8 GEMMs (csrc/gemm_ring.hip F8 variant, csrc/elementwise.hip quantisers): BASELINE configs[4] -----------------
+ * C[m][n] = alpha * (*scale_a) * (*scale_b) * sum_k A8(m,k) B8(n,k) with the epilogues of dcc_gemm, bf16 output, computed
+ * by the block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; per-tensor scales in alpha).  A8 [M,K] and
+ * B8 [N,K] are k-contiguous fp8 bytes (fmt 0 = OCP e4m3, 1 = e5m2), K % 16 == 0, K > 128.  Replaces the same torch
+ * Linear layers as dcc_gemm when the encoder runs its forward / data-gradient GEMMs in fp8. */
+int dcc_gemm_fp8(const void* A8, const void* B8, void* C, const float* bias, const void* R, void* aux,
+                 const float* scale_a, const float* scale_b, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr,
+                 int64_t ldaux, int M, int N, int K, float alpha, int flags, int fmt_a, int fmt_b, void* stream);
+/* amax[0] = max(amax[0], max |x|) over a [rows, cols] view (row pitch ldx); amax zero-initialised by the caller. */
+int dcc_absmax(const void* x, int64_t rows, int64_t cols, int64_t ldx, int dtype, float* amax, void* stream);
+/* out8 = fp8(x * FMAX / *amax) (transpose != 0: out8[c][r]); scale_out[0] = *amax / FMAX. */
+int dcc_fp8_quantize(const void* x, int64_t rows, int64_t cols, int64_t ldx, int dtype, const float* amax, void* out8,
+                     int64_t ldo, int transpose, int fmt, float* scale_out, void* stream);
+
 /* ---- flash attention (csrc/attention.hip) ---------------------------------------------------
  * O = softmax(scale * Qf Kf^T + kbias) V (+ Qres[q][0:DV] for q >= res_start); LSE[B,H,Nq] kept.
  * Operands are [B, N, H, D] views; strides = {q_b,q_n,q_h, k_b,k_n,k_h, v_b,v_n,v_h, o_b,o_n,o_h}.

@@ -320,6 +320,8 @@ def test_embedding_cache_two_pass_equals_one_shot(loss_name):
         if p.grad is None:
             assert pb[n].grad is None or float(pb[n].grad.abs().max()) == 0.0, n
             continue
+        if "pool_k.norm_act.0.bias" in n:
+            continue  # analytically zero gradient (a uniform shift of a softmax row): both sides hold summation noise
         err = float((p.grad - pb[n].grad).norm() / p.grad.norm().clamp_min(floor))
         worst = max(worst, err)
         assert err < 2e-4, (n, err)
