@@ -336,6 +336,15 @@ __global__ void scale_by_dev_kernel(float* __restrict__ x, int64_t n, const floa
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= c;
 }
 
+// ReLU (nn.TransformerEncoderLayer's default activation inside AttentionPoolWithCLS): y = max(x, 0); dx = dy * [y > 0]
+template <typename T>
+__global__ void relu_kernel(const T* __restrict__ x, const T* __restrict__ gate, T* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = to_f32(gate ? gate[i] : x[i]);
+    y[i] = g > 0.0f ? x[i] : from_f32<T>(0.0f);
+  }
+}
+
 // ---- fp8 quantisation (per-tensor scale) for the fp8 GEMMs of BASELINE configs[4] ------------------------------------
 // amax[0] = max(amax[0], max |x|): float bit patterns of non-negative values order like unsigned integers
 template <typename T>
@@ -396,6 +405,15 @@ __global__ __launch_bounds__(256) void fp8_quant_t_kernel(const T* __restrict__ 
 
 #define ST (hipStream_t) stream
 
+// gate == NULL: y = relu(x);  gate != NULL: y = x * [gate > 0]  (backward with gate = the forward output)
+extern "C" int dcc_relu(const void* x, const void* gate, void* y, int64_t n, int dtype, void* stream) {
+  if (!x || !y || n <= 0) return DCC_ERR_ARG;
+  dim3 g(gs_blocks(n, 4));
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((relu_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)gate, (bf16_t*)y, n);
+  else if (dtype == DCC_F32) hipLaunchKernelGGL((relu_kernel<float>), g, dim3(256), 0, ST, (const float*)x, (const float*)gate, (float*)y, n);
+  else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
 extern "C" int dcc_absmax(const void* x, int64_t rows, int64_t cols, int64_t ldx, int dtype, float* amax, void* stream) {
   if (!x || !amax || rows <= 0 || cols <= 0) return DCC_ERR_ARG;
   dim3 g(gs_blocks(rows * cols, 8));

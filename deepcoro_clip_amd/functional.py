@@ -748,6 +748,51 @@ def add(a, b):
     return AddFn.apply(a, b)
 
 
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = K.relu(_c(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, d):
+        (y,) = ctx.saved_tensors
+        return K.relu(_c(d), y)
+
+
+def relu(x):
+    return ReluFn.apply(x)
+
+
+class PrependTokenFn(torch.autograd.Function):
+    """cat([token.expand(B, 1, D), x], dim=1) for x [B, N, D] and a learnable token [1, 1, D] (AttentionPoolWithCLS)."""
+
+    @staticmethod
+    def forward(ctx, token, x):
+        B, N, D = x.shape
+        out = torch.empty((B, N + 1, D), device=x.device, dtype=x.dtype)
+        K.broadcast_row(_c(token.detach().float()).view(-1), out, (N + 1) * D, B)
+        K.cast2d(_c(x).view(B, N * D), out.view(B, (N + 1) * D)[:, D:])
+        ctx.shape = (B, N, D)
+        ctx.tshape = token.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        B, N, D = ctx.shape
+        d = _c(d)
+        d2 = d.view(B, (N + 1) * D)
+        dx = torch.empty((B, N * D), device=d.device, dtype=d.dtype)
+        K.cast2d(d2[:, D:], dx)
+        dtok = K.colsum(d2[:, :D]).view(ctx.tshape)
+        return dtok, dx.view(B, N, D)
+
+
+def prepend_token(token, x):
+    return PrependTokenFn.apply(token, x)
+
+
 class StochasticDepthFn(torch.autograd.Function):
     """out = resid + branch * scale[sample]  (torchvision StochasticDepth, mode "row", fused with the residual add)."""
 

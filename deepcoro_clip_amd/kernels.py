@@ -785,3 +785,12 @@ def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, sa: torch.Tensor, sb: torch.Ten
                a8.stride(0), b8.stride(0), out.stride(0), resid.stride(0) if resid is not None else 0,
                aux.stride(0) if aux is not None else 0, M, N, K, float(alpha), flags, int(fmt_a), int(fmt_b), L.stream())
     return out
+
+
+def relu(x: torch.Tensor, gate: torch.Tensor | None = None) -> torch.Tensor:
+    """gate None: max(x, 0); else x * [gate > 0] (the backward form, gate = forward output)."""
+    L.require_cuda(x, gate)
+    assert x.is_contiguous() and (gate is None or (gate.is_contiguous() and gate.shape == x.shape and gate.dtype == x.dtype))
+    out = torch.empty_like(x)
+    L.call("dcc_relu", L.ptr(x), L.ptr(gate), L.ptr(out), x.numel(), L.dt(x), L.stream())
+    return out

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
-from .attention_pool import AttentionPool
+from .attention_pool import AttentionPool, AttentionPoolWithCLS
 from .mvit import HipMViT
 from .registry import ModelRegistry
 from .video_aggregator import EnhancedVideoAggregator
@@ -113,7 +113,7 @@ class VideoEncoder(nn.Module):
         if token_pooling_mode == "attention":
             self.attention_pool = AttentionPool(embed_dim=output_dim, num_heads=attention_pool_heads, dropout=attention_pool_dropout)
         elif token_pooling_mode == "cls_token":
-            raise NotImplementedError("token_pooling_mode='cls_token' (AttentionPoolWithCLS) is a secondary variant not on the HIP path")
+            self.attention_pool = AttentionPoolWithCLS(embed_dim=output_dim, num_heads=attention_pool_heads, dropout=attention_pool_dropout)
 
     # ------------------------------------------------------------------ checkpoint / freezing (host logic)
     def _load_encoder_checkpoint(self):

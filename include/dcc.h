@@ -174,6 +174,9 @@ int dcc_nan_to_num(void* x, int64_t n, float nanv, float posv, float negv, int* 
 int dcc_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const int64_t* step, int dtype, void* stream);
 int dcc_scale_by_dev(float* x, int64_t n, const float* coef, void* stream);
 
+/* ReLU of nn.TransformerEncoderLayer (models/attention_pool.py:139-147): gate NULL -> y = max(x, 0); else y = x * [gate > 0]. */
+int dcc_relu(const void* x, const void* gate, void* y, int64_t n, int dtype, void* stream);
+
 /* ---- contrastive losses (csrc/loss.hip); scal = fp32[8]
  * {0 loss, 1 dlog_temp, 2 dbias, 3 mean diag log-softmax, 4 mean diag cosine, 5 sum ||v||, 6 sum ||t||, 7 -} */
 int dcc_l2norm_fwd(const float* x, int64_t ldx, float* y, float* norms, int R, int D, float eps, float* norm_sum,

@@ -79,6 +79,44 @@ class AttentionPoolOracle(nn.Module):
         return self.norm(o).squeeze(1)
 
 
+class _EncLayerParams(nn.Module):
+    """nn.TransformerEncoderLayer parameter names (post-norm, ReLU feed-forward)."""
+
+    def __init__(self, dim, ffn):
+        super().__init__()
+        self.self_attn = _MHAParams(dim)
+        self.linear1 = nn.Linear(dim, ffn)
+        self.linear2 = nn.Linear(ffn, dim)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+
+
+class _EncStack(nn.Module):
+    def __init__(self, n, dim, ffn):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncLayerParams(dim, ffn) for _ in range(n)])
+
+
+class AttentionPoolWithCLSOracle(nn.Module):
+    """models/attention_pool.py:104-197 restated: CLS token + post-norm nn.TransformerEncoderLayer blocks (ReLU FFN 2048)
+    + LayerNorm on the CLS output; parameter names of the reference's state_dict."""
+
+    def __init__(self, embed_dim=512, num_heads=8, num_layers=1):
+        super().__init__()
+        self.num_heads = num_heads
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.transformer = _EncStack(num_layers, embed_dim, 2048)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x):
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1)
+        for l in self.transformer.layers:
+            a = l.self_attn
+            x = l.norm1(x + mha_forward(x, x, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, self.num_heads))
+            x = l.norm2(x + l.linear2(F.relu(l.linear1(x))))
+        return self.norm(x[:, 0])
+
+
 class _AggBlock(nn.Module):
     def __init__(self, dim, heads):
         super().__init__()
@@ -123,7 +161,8 @@ class VideoEncoderOracle(nn.Module):
             enable_rope(self.model, rope_base, rope_temporal_scale)
         self.proj = nn.Sequential(nn.Dropout(0.0), nn.Linear(768, output_dim), nn.GELU(), nn.Dropout(0.0))
         self.aggregator = AggregatorOracle(output_dim, num_heads, aggregator_depth)
-        self.attention_pool = AttentionPoolOracle(output_dim, attention_pool_heads) if token_pooling_mode == "attention" else None
+        self.attention_pool = AttentionPoolOracle(output_dim, attention_pool_heads) if token_pooling_mode == "attention" else (
+            AttentionPoolWithCLSOracle(output_dim, attention_pool_heads) if token_pooling_mode == "cls_token" else None)
         self._apply_aggregator, self._per_video_pool = aggregate_videos_tokens, per_video_pool
 
     def features(self, x):

@@ -198,6 +198,17 @@ def retrieval():
     np.savez_compressed(os.path.join(OUT, "retrieval.npz"), **out)
 
 
+def pools2():
+    """AttentionPoolWithCLS (models/attention_pool.py:104-197; token_pooling_mode='cls_token')."""
+    AP = load_by_path("ref_attention_pool", "models/attention_pool.py")
+    g = torch.Generator().manual_seed(9)
+    m = init_by_name(AP.AttentionPoolWithCLS(512, num_heads=8, dropout=0.0)).eval()
+    x = torch.randn(2, 50, 512, generator=g)
+    with torch.no_grad():
+        y = m(x)
+    np.savez_compressed(os.path.join(OUT, "pools2.npz"), apcls_x=np_(x), apcls_y=np_(y), keys=np.array(sorted(m.state_dict().keys())))
+
+
 def loss_zoo():
     """Remaining loss zoo: auto-balance / entropy-regularised contrastive.SigLIPLoss,
     siglip_pairwise.SiglipPairwiseFeatureLoss, multi_positive_infonce.MultiPositiveInfoNCELoss, and the runner's
@@ -275,7 +286,7 @@ def loss_zoo():
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (losses, rope, pools, bert, retrieval, loss_zoo):
+    for fn in (losses, rope, pools, bert, retrieval, loss_zoo, pools2):
         if only and fn.__name__ not in only:
             continue
         fn()

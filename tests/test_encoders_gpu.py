@@ -43,7 +43,7 @@ def _grad_check(prod, orc, names_tol, default_tol, floor_frac=1e-2):
 
 
 @pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 5e-2, 2e-1)])
-@pytest.mark.parametrize("pooling,N", [("mean", 0), ("attention", 2)])
+@pytest.mark.parametrize("pooling,N", [("mean", 0), ("attention", 2), ("cls_token", 2)])
 def test_video_encoder_vs_oracle(dtype, tol, gtol, pooling, N):
     from deepcoro_clip_amd.video_encoder import VideoEncoder
     from oracle.model import VideoEncoderOracle, init_by_name
@@ -220,3 +220,22 @@ def test_full_size_properties_16x224():
     ref = -(torch.diagonal(torch.log_softmax(sim, dim=1)).mean() + torch.diagonal(torch.log_softmax(sim.t(), dim=1)).mean()) / 2
     assert abs(crit(e, e, lt).item() - ref.item()) < 1e-4 * max(1.0, abs(ref.item()))
     assert math.isfinite(ref.item())
+
+
+def test_attention_pool_with_cls_matches_reference_golden():
+    """AttentionPoolWithCLS (token_pooling_mode='cls_token') on the HIP path vs the golden produced by the reference module
+    (tests/golden/pools2.npz), fp32 compute; state_dict names are the reference's (nn.TransformerEncoder inside)."""
+    import os
+
+    import numpy as np
+    from deepcoro_clip_amd.attention_pool import AttentionPoolWithCLS
+    from oracle.model import AttentionPoolWithCLSOracle, init_by_name
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pools2.npz"))
+    orc = init_by_name(AttentionPoolWithCLSOracle(512, 8))
+    m = AttentionPoolWithCLS(512, num_heads=8, dropout=0.0)
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    m.load_state_dict(orc.state_dict())
+    m = m.cuda().eval()
+    y = m(torch.from_numpy(g["apcls_x"]).cuda())
+    assert _rel(y.cpu(), torch.from_numpy(g["apcls_y"])) < 2e-4

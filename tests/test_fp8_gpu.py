@@ -28,7 +28,7 @@ def test_fp8_quantize_matches_torch_float8(fmt, dtype):
     same = (q == ref).float().mean().item()
     assert same > 0.999, same  # round-to-nearest-even on both sides; ties on the scaled value may differ by the fp32 product
     d = (_deq(q, scale, fmt) - x.float()).abs() / x.float().abs().clamp_min(1e-3)
-    assert d.max() < (0.07 if fmt == 0 else 0.13)
+    assert d.max() < (0.08 if fmt == 0 else 0.15)
     qt, st = K.fp8_quantize(x[:, :128].contiguous(), fmt, transpose=True)
     q2, _ = K.fp8_quantize(x[:, :128].contiguous(), fmt)
     assert qt.shape == (128, 300) and torch.equal(qt.t().contiguous(), q2)

@@ -178,3 +178,37 @@ def test_retrieval_metrics_host_part_matches_golden():
     assert [RM.recall_from_ranks(r2, k) for k in (1, 3, 5)] == pytest.approx(list(g["recall2"]))
     with pytest.raises(Exception):  # the full functions need the GPU rank kernel: no CPU path
         RM.compute_recall_at_k(torch.from_numpy(g["sim"]), torch.arange(100), [1])
+
+
+def test_encoder_checkpoint_round_trip(tmp_path):
+    """`encoder_path` loading (models/video_encoder.py:390-440): checkpoints wrapped in `model_state_dict` / `state_dict`,
+    `module.` / `model.` prefixes stripped, decoder / mvm / mask_token / head tensors skipped, strict=False semantics;
+    and the runner's checkpoint file is loadable back into fresh encoders (reference layout, :1071-1115)."""
+    import torch
+
+    from deepcoro_clip_amd.video_encoder import VideoEncoder
+
+    src = VideoEncoder(num_frames=4, spatial_size=(64, 64), pretrained=False, freeze_ratio=1.0, dropout=0.0)
+    sd = {}
+    for k, v in src.model.state_dict().items():
+        sd["module.model." + k] = v.clone() + 0.25           # as saved from a DDP-wrapped pre-training model
+    sd["module.decoder.weight"] = torch.zeros(3)             # pre-training-only tensors must be ignored
+    sd["module.mask_token"] = torch.zeros(1, 1, 96)
+    sd["module.model.head.1.weight"] = torch.zeros(400, 768)
+    for wrap in ("model_state_dict", "state_dict", None):
+        path = tmp_path / f"enc_{wrap}.pt"
+        torch.save({wrap: sd, "epoch": 3} if wrap else sd, path)
+        dst = VideoEncoder(num_frames=4, spatial_size=(64, 64), pretrained=False, freeze_ratio=1.0, dropout=0.0, encoder_path=str(path))
+        for (k, a), (_, b) in zip(dst.model.state_dict().items(), src.model.state_dict().items()):
+            assert torch.equal(a, b + 0.25), (wrap, k)
+    # a missing file is reported, not fatal (reference prints and continues)
+    VideoEncoder(num_frames=4, spatial_size=(64, 64), pretrained=False, encoder_path=str(tmp_path / "nope.pt"))
+    # the full-encoder state dict (what _save_checkpoint writes) round-trips, proj / aggregator / attention_pool included
+    full = VideoEncoder(num_frames=4, spatial_size=(64, 64), pretrained=False, token_pooling_mode="cls_token", dropout=0.0)
+    ck = tmp_path / "checkpoint.pt"
+    torch.save({"video_encoder": full.state_dict(), "epoch": 0, "best_val_loss": 1.0, "best_epoch": 0,
+                "highest_alignment_score": 0.5, "highest_alignment_epoch": 0}, ck)
+    other = VideoEncoder(num_frames=4, spatial_size=(64, 64), pretrained=False, token_pooling_mode="cls_token", dropout=0.0)
+    missing, unexpected = other.load_state_dict(torch.load(ck)["video_encoder"], strict=True)
+    assert not missing and not unexpected
+    assert any(k.startswith("attention_pool.transformer.layers.0.self_attn.in_proj_weight") for k in full.state_dict())

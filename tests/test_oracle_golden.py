@@ -229,3 +229,19 @@ def test_loss_zoo_oracle_matches_reference():
         assert abs(loss.item() - float(g[f"{name}_loss"])) < 1e-5 * max(1.0, abs(float(g[f"{name}_loss"]))), name
         assert (z.grad - T(f"{name}_dz")).norm() <= 1e-4 * T(f"{name}_dz").norm(), name
     assert OL.multi_positive_infonce(T("nce_logits"), torch.zeros(8, 13)).item() == float(g["nce_empty_loss"]) == 0.0
+
+
+def test_attention_pool_with_cls_oracle_matches_reference():
+    """tests/golden/pools2.npz: models/attention_pool.py AttentionPoolWithCLS (nn.TransformerEncoder inside) with
+    name-seeded weights; the oracle restates it with explicit ops under the same state_dict names."""
+    import os
+
+    import numpy as np
+    from oracle.model import AttentionPoolWithCLSOracle, init_by_name
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pools2.npz"))
+    m = init_by_name(AttentionPoolWithCLSOracle(512, 8)).eval()
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["apcls_x"]))
+    assert (y - torch.from_numpy(g["apcls_y"])).abs().max() < 2e-5
