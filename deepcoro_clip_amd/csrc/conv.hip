@@ -64,24 +64,32 @@ struct Im2colGeom {
   unsigned ntok, xbytes;
   FastDiv d_cpt, d_Wo, d_Ho, d_To;
 };
-template <typename T>
-__global__ __launch_bounds__(256) void im2col3d_chunk_kernel(const float* __restrict__ x, T* __restrict__ col, Im2colGeom g) {
+// TI = float: frames already normalised (the reference's host pipeline); TI = uint8_t: raw pixels, (x - mean[c]) / std[c]
+// is applied here (utils/video.py:278-288 on the fly: no fp32 copy of the clip ever exists, 4x less H2D traffic).  Padding
+// taps are zeros of the NORMALISED tensor in both cases (Conv3d pads after the transform).
+template <typename T, typename TI>
+__global__ __launch_bounds__(256) void im2col3d_chunk_kernel(const TI* __restrict__ x, T* __restrict__ col, Im2colGeom g,
+                                                             const float* __restrict__ mean, const float* __restrict__ stdv) {
   constexpr int CV = Vec16<T>::N;
+  constexpr bool U8 = sizeof(TI) == 1;
   const unsigned tl = fdiv(threadIdx.x, g.d_cpt);
   const int ch = threadIdx.x - tl * g.cpt;
   if ((int)tl >= g.tpb) return;
   const int run = g.KW * g.Cin, K = g.KT * g.KH * run;
   int doff[CV], kt[CV], kh[CV], kw[CV];
+  float nsub[CV], nmul[CV];
 #pragma unroll
   for (int e = 0; e < CV; ++e) {
     const int i = ch * CV + e;
+    nsub[e] = 0.0f; nmul[e] = 1.0f;
     if (i < K) {
       const int r = i % run;
       kh[e] = (i / run) % g.KH; kt[e] = i / (run * g.KH); kw[e] = r / g.Cin;
       doff[e] = ((kt[e] * g.Hn + kh[e]) * g.Wn + kw[e]) * g.Cin + (r % g.Cin);
+      if constexpr (U8) { nsub[e] = mean[r % g.Cin]; nmul[e] = 1.0f / stdv[r % g.Cin]; }
     } else { kt[e] = 1 << 20; kh[e] = kw[e] = doff[e] = 0; }  // zero padding of the column index: never in range
   }
-  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<TI*>(x), 0, (int)g.xbytes, 0x00020000);
   for (unsigned tok = blockIdx.x * g.tpb + tl; tok < g.ntok; tok += gridDim.x * g.tpb) {
     const unsigned q1 = fdiv(tok, g.d_Wo);
     const int wo = tok - q1 * g.Wo;
@@ -95,7 +103,12 @@ __global__ __launch_bounds__(256) void im2col3d_chunk_kernel(const float* __rest
 #pragma unroll
     for (int e = 0; e < CV; ++e) {
       const bool ok = (unsigned)(t0 + kt[e]) < (unsigned)g.Tn && (unsigned)(h0 + kh[e]) < (unsigned)g.Hn && (unsigned)(w0 + kw[e]) < (unsigned)g.Wn;
-      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, ok ? (unsigned)(obase + doff[e]) * 4u : 0xF0000000u, 0, 0));
+      if constexpr (U8) {
+        const unsigned raw = __builtin_amdgcn_raw_buffer_load_b8(rsx, ok ? (unsigned)(obase + doff[e]) : 0xF0000000u, 0, 0);
+        v[e] = ok ? ((float)(raw & 0xffu) - nsub[e]) * nmul[e] : 0.0f;
+      } else {
+        v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, ok ? (unsigned)(obase + doff[e]) * 4u : 0xF0000000u, 0, 0));
+      }
     }
     T* dst = col + (int64_t)tok * g.Kp + ch * CV;
     if constexpr (sizeof(T) == 2) {
@@ -1279,8 +1292,8 @@ extern "C" int dcc_im2col3d(const float* x, void* col, int B, int T, int H, int 
       g.d_cpt = mkdiv(g.cpt); g.d_Wo = mkdiv(Wo); g.d_Ho = mkdiv(Ho); g.d_To = mkdiv(To);
       int64_t nb = (ntok + g.tpb - 1) / g.tpb;
       if (nb > 16384) nb = 16384;
-      if (dtype == DCC_BF16) hipLaunchKernelGGL((im2col3d_chunk_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, s, x, (bf16_t*)col, g);
-      else hipLaunchKernelGGL((im2col3d_chunk_kernel<float>), dim3((unsigned)nb), dim3(256), 0, s, x, (float*)col, g);
+      if (dtype == DCC_BF16) hipLaunchKernelGGL((im2col3d_chunk_kernel<bf16_t, float>), dim3((unsigned)nb), dim3(256), 0, s, x, (bf16_t*)col, g, nullptr, nullptr);
+      else hipLaunchKernelGGL((im2col3d_chunk_kernel<float, float>), dim3((unsigned)nb), dim3(256), 0, s, x, (float*)col, g, nullptr, nullptr);
       return dcc_check_launch();
     }
   }
@@ -1291,6 +1304,30 @@ extern "C" int dcc_im2col3d(const float* x, void* col, int B, int T, int H, int 
     hipLaunchKernelGGL((im2col3d_kernel<float>), grid, dim3(256), 0, s, x, (float*)col, B, T, H, W, Cin, KT, KH, KW, st,
                        sh, sw, pt, ph, pw, To, Ho, Wo, Kp);
   else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+// uint8 frames + per-channel mean / std (pixel units) -> normalised im2col rows; same column order as dcc_im2col3d
+extern "C" int dcc_im2col3d_u8(const uint8_t* x, const float* mean, const float* stdv, void* col, int B, int T, int H, int W,
+                               int Cin, int KT, int KH, int KW, int st, int sh, int sw, int pt, int ph, int pw, int Kp,
+                               int dtype, void* stream) {
+  if (!x || !mean || !stdv || !col || B <= 0) return DCC_ERR_ARG;
+  const int To = (T + 2 * pt - KT) / st + 1, Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
+  if (Kp < KT * KH * KW * Cin) return DCC_ERR_ARG;
+  const int64_t ntok = (int64_t)B * To * Ho * Wo;
+  const int cv = dtype == DCC_BF16 ? 8 : 4;
+  const int64_t xelems = (int64_t)B * T * H * W * Cin;
+  if (!(dtype == DCC_BF16 || dtype == DCC_F32) || Kp % cv || Kp / cv > 256 || xelems >= 0x7fffffffLL || ntok >= (1LL << 30) ||
+      (((uintptr_t)col) & 15))
+    return DCC_ERR_UNSUPPORTED;
+  Im2colGeom g{B, T, H, W, Cin, KT, KH, KW, st, sh, sw, pt, ph, pw, To, Ho, Wo, Kp};
+  g.cpt = Kp / cv; g.tpb = 256 / g.cpt; g.ntok = (unsigned)ntok; g.xbytes = (unsigned)xelems;
+  g.d_cpt = mkdiv(g.cpt); g.d_Wo = mkdiv(Wo); g.d_Ho = mkdiv(Ho); g.d_To = mkdiv(To);
+  int64_t nb = (ntok + g.tpb - 1) / g.tpb;
+  if (nb > 16384) nb = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DCC_BF16) hipLaunchKernelGGL((im2col3d_chunk_kernel<bf16_t, uint8_t>), dim3((unsigned)nb), dim3(256), 0, s, x, (bf16_t*)col, g, mean, stdv);
+  else hipLaunchKernelGGL((im2col3d_chunk_kernel<float, uint8_t>), dim3((unsigned)nb), dim3(256), 0, s, x, (float*)col, g, mean, stdv);
   return dcc_check_launch();
 }
 

@@ -649,14 +649,14 @@ class PatchEmbedFn(torch.autograd.Function):
     (models/video_encoder.py:237-241) as im2col + batched MFMA GEMM writing rows 1.. of each clip."""
 
     @staticmethod
-    def forward(ctx, video, weight, bias, cls_token, dtype):
-        # video: [B', T, H, W, Cin] fp32 (NDHWC memory)
+    def forward(ctx, video, weight, bias, cls_token, dtype, norm=None):
+        # video: [B', T, H, W, Cin] fp32 (NDHWC memory), or uint8 raw pixels with norm = (mean, std)
         Bp = video.shape[0]
         Cout, Cin, kt, kh, kw = weight.shape
         stride, padding = (2, 4, 4), (1, 3, 3)
         Kc = Cin * kt * kh * kw
         Kp = 32 * ((Kc + 31) // 32)
-        col = K.im2col3d(_c(video), (kt, kh, kw), stride, padding, Kp, dtype)
+        col = K.im2col3d(_c(video), (kt, kh, kw), stride, padding, Kp, dtype, norm)
         L_ = col.shape[0] // Bp
         # weight in (kt,kh,kw,cin) column order, zero padded (tiny host-side view op on 42k elements)
         w2 = torch.zeros((Cout, Kp), device=video.device, dtype=torch.float32)
@@ -690,11 +690,11 @@ class PatchEmbedFn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             db_all = K.colsum(dy3.view(Bp * (L_ + 1), Cout))
             db = K.axpby(db_all, dcls_sum, 1.0, -1.0)
-        return None, dw, db, dcls, None
+        return None, dw, db, dcls, None, None
 
 
-def patch_embed(video, weight, bias, cls_token, dtype):
-    return PatchEmbedFn.apply(video, weight, bias, cls_token, dtype)
+def patch_embed(video, weight, bias, cls_token, dtype, norm=None):
+    return PatchEmbedFn.apply(video, weight, bias, cls_token, dtype, norm)
 
 
 # ----------------------------------------------------------------------------------- small ops

@@ -359,13 +359,24 @@ def dwconv_bwd_weight(dy: torch.Tensor, x: torch.Tensor, g: PoolGeom, dw: torch.
     return dw
 
 
-def im2col3d(video: torch.Tensor, kernel, stride, padding, kp: int, dtype: torch.dtype) -> torch.Tensor:
-    """video: [B, T, H, W, C] fp32 contiguous -> [B*To*Ho*Wo, kp] in `dtype`, column order (kt,kh,kw,c)."""
+def im2col3d(video: torch.Tensor, kernel, stride, padding, kp: int, dtype: torch.dtype, norm=None) -> torch.Tensor:
+    """video: [B, T, H, W, C] contiguous, fp32 (already normalised) or uint8 with norm = (mean[C], std[C]) fp32 device
+    tensors in pixel units -> [B*To*Ho*Wo, kp] in `dtype`, column order (kt,kh,kw,c)."""
     L.require_cuda(video)
-    assert video.dtype == torch.float32 and video.is_contiguous() and video.dim() == 5
+    assert video.is_contiguous() and video.dim() == 5
     B, T, H, W, C = video.shape
     To, Ho, Wo = [(s + 2 * p - k) // st + 1 for s, p, k, st in zip((T, H, W), padding, kernel, stride)]
     col = torch.empty((B * To * Ho * Wo, kp), device=video.device, dtype=dtype)
+    if video.dtype == torch.uint8:
+        if norm is None:
+            raise L.DccError("uint8 frames need the per-channel (mean, std) of the input normalisation")
+        mean, std = norm
+        L.require_cuda(mean, std)
+        assert mean.dtype == std.dtype == torch.float32 and mean.numel() == C and std.numel() == C
+        L.call("dcc_im2col3d_u8", L.ptr(video), L.ptr(mean), L.ptr(std), L.ptr(col), B, T, H, W, C, *kernel, *stride, *padding,
+               kp, L.dt(dtype), L.stream())
+        return col
+    assert video.dtype == torch.float32
     L.call("dcc_im2col3d", L.ptr(video), L.ptr(col), B, T, H, W, C, *kernel, *stride, *padding, kp, L.dt(dtype),
            L.stream())
     return col

@@ -236,13 +236,14 @@ class HipMViT(nn.Module):
             self._rope_cache[key] = dict(cos_q=cq.to(device), sin_q=sq.to(device), cos_k=ck.to(device), sin_k=sk.to(device))
         return self._rope_cache[key]
 
-    def forward_features(self, video: torch.Tensor, compute_dtype: torch.dtype) -> torch.Tensor:
-        """video: [B', T, H, W, 3] fp32 (channels-last, as the dataset collates it) -> [B', L, 768]."""
+    def forward_features(self, video: torch.Tensor, compute_dtype: torch.dtype, norm=None) -> torch.Tensor:
+        """video: [B', T, H, W, 3] fp32 (channels-last, as the dataset collates it), or uint8 raw pixels with
+        norm = (mean[3], std[3]) applied inside the patch gather -> [B', L, 768]."""
         K.L.require_cuda(video)
         Bp, T, H, W, C = video.shape
         if (T, H, W) != (self.temporal_size, *self.spatial_size):
             raise ValueError(f"MViT built for {(self.temporal_size, *self.spatial_size)} got {(T, H, W)}")
-        x = Fn.patch_embed(video, self.conv_proj.weight, self.conv_proj.bias, self.pos_encoding.class_token, compute_dtype)
+        x = Fn.patch_embed(video, self.conv_proj.weight, self.conv_proj.bias, self.pos_encoding.class_token, compute_dtype, norm)
         for blk in self.blocks:
             x = blk.forward_tokens(x, Bp, rope=self._rope(blk, video.device))
         x = Fn.layernorm(x, self.norm.weight, self.norm.bias, self.eps)

@@ -184,13 +184,21 @@ class VideoContrastiveLearningRunner:
             mean, std = _cfg(self.config, "video_mean", None), _cfg(self.config, "video_std", None)
             if mean is None or std is None:
                 raise ValueError("uint8 videos need config.video_mean / config.video_std (per-channel, pixel units)")
-            C = videos.shape[-1]
-            as_vec = lambda v: torch.tensor([float(v)] * C if isinstance(v, (int, float)) else [float(x) for x in v][:C],  # noqa: E731
-                                            dtype=torch.float32, device=videos.device)
-            videos = K.u8_normalize(videos.contiguous(), as_vec(mean), as_vec(std))
+            enc = self.video_encoder.module if hasattr(self.video_encoder, "module") else self.video_encoder
+            if hasattr(enc, "set_input_normalization"):
+                # bytes all the way into the patch-embedding gather: normalised on the fly, no fp32 copy of the clip
+                if getattr(enc, "input_norm", None) is None:
+                    enc.set_input_normalization(mean, std)
+                videos = videos.contiguous()
+            else:
+                C = videos.shape[-1]
+                as_vec = lambda v: torch.tensor([float(v)] * C if isinstance(v, (int, float)) else [float(x) for x in v][:C],  # noqa: E731
+                                                dtype=torch.float32, device=videos.device)
+                videos = K.u8_normalize(videos.contiguous(), as_vec(mean), as_vec(std))
         elif videos.dtype != torch.float32:
             videos = K.cast(videos.contiguous(), torch.float32)
-        videos = K.nan_to_num_(videos.contiguous(), 0.0, 0.0, 0.0)
+        if videos.dtype != torch.uint8:
+            videos = K.nan_to_num_(videos.contiguous(), 0.0, 0.0, 0.0)
         step_inputs: Dict[str, Any] = {"videos": videos}
         enc = batch.get("encoded_texts")
         if enc is not None:

@@ -70,6 +70,7 @@ class VideoEncoder(nn.Module):
             raise ValueError(f"gemm_dtype must be 'bf16' or 'fp8', got {gemm_dtype!r}")
         if gemm_dtype == "fp8" and compute_dtype != torch.bfloat16:
             raise ValueError("gemm_dtype='fp8' runs on bf16 activations: use compute_dtype=torch.bfloat16")
+        self.input_norm = None  # (mean[3], std[3]) device tensors: set_input_normalization(); lets forward() take uint8 frames
         self.gemm_dtype = gemm_dtype  # "fp8": forward / data-gradient GEMMs of the trunk on the fp8 MFMA (BASELINE configs[4])
 
         if backbone in ("mvit", "mvit_rope"):
@@ -150,6 +151,15 @@ class VideoEncoder(nn.Module):
         print(f"[VideoEncoder] Updated freeze_ratio from {old:.2f} to {new_freeze_ratio:.2f}")
         print(f"[VideoEncoder] Trainable parameters: {trainable:,} / {total:,} ({100.0 * trainable / max(total, 1):.1f}%)")
 
+    def set_input_normalization(self, mean, std) -> None:
+        """Per-channel mean / std in pixel units (the dataset's, utils/video.py:278-288).  With them set, `forward` accepts
+        raw uint8 frames: the normalisation happens inside the patch-embedding gather (dcc_im2col3d_u8), the clip crosses
+        PCIe as bytes and is never materialised in fp32."""
+        dev = self.proj[1].weight.device
+        as_vec = lambda v: torch.tensor([float(v)] * 3 if isinstance(v, (int, float)) else [float(x) for x in v][:3],  # noqa: E731
+                                        dtype=torch.float32, device=dev)
+        self.input_norm = (as_vec(mean), as_vec(std))
+
     @property
     def embedding_dim(self) -> int:
         return self._embedding_dim
@@ -170,8 +180,13 @@ class VideoEncoder(nn.Module):
 
     def _extract_backbone_features(self, x: torch.Tensor) -> torch.Tensor:
         """x: [B*N, T, H, W, C] fp32 channels-last -> [B*N, L, 768] (class token included, as in the reference)."""
+        norm = None
+        if x.dtype == torch.uint8:
+            if self.input_norm is None:
+                raise ValueError("uint8 frames need VideoEncoder.set_input_normalization(mean, std) (pixel units)")
+            norm = tuple(t.to(x.device) for t in self.input_norm)
         with Fn.fp8_gemms(self.gemm_dtype == "fp8"):
-            return self.model.forward_features(x, self.compute_dtype)
+            return self.model.forward_features(x, self.compute_dtype, norm)
 
     def _compute_feature_dict(self, x: torch.Tensor, compute_aggregated: bool) -> Dict[str, torch.Tensor]:
         if x.ndim == 5:
@@ -180,7 +195,7 @@ class VideoEncoder(nn.Module):
             s = x.shape
             x = x.view(s[0], s[1] * s[2], s[3], s[4], s[5], s[6])
         B, N, T, H, W, C = x.shape
-        if x.dtype != torch.float32:
+        if x.dtype not in (torch.float32, torch.uint8):
             x = Fn.cast(x.contiguous(), torch.float32)
         clips = x.reshape(B * N, T, H, W, C)  # the reference permutes to NCTHW as a VIEW; memory stays channels-last
         tok = self._extract_backbone_features(clips)

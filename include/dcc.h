@@ -131,6 +131,11 @@ int dcc_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, 
  *   mode 0 = depthwise conv (w [C][taps] fp32), mode 1 = max pool (argmax uint8 [B,No,H,C]). */
 int dcc_im2col3d(const float* x, void* col, int B, int T, int H, int W, int Cin, int KT, int KH, int KW, int st,
                  int sh, int sw, int pt, int ph, int pw, int Kp, int dtype, void* stream);
+/* Same rows from raw uint8 frames: (pixel - mean[c]) / std[c] (utils/video.py:278-288) is applied inside the gather, so
+ * the clip crosses PCIe as bytes and no normalised fp32 copy is ever written. */
+int dcc_im2col3d_u8(const uint8_t* x, const float* mean, const float* stdv, void* col, int B, int T, int H, int W, int Cin,
+                    int KT, int KH, int KW, int st, int sh, int sw, int pt, int ph, int pw, int Kp, int dtype,
+                    void* stream);
 int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* argmax, const int* dims, const int64_t* strides,
                  int mode, int dtype, void* stream);
 int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const uint8_t* argmax, const int* dims,

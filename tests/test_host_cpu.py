@@ -212,3 +212,51 @@ def test_encoder_checkpoint_round_trip(tmp_path):
     missing, unexpected = other.load_state_dict(torch.load(ck)["video_encoder"], strict=True)
     assert not missing and not unexpected
     assert any(k.startswith("attention_pool.transformer.layers.0.self_attn.in_proj_weight") for k in full.state_dict())
+
+
+def test_collate_layouts_and_text_bucketing():
+    """custom_collate_fn (dataloaders/video_clip_dataset.py:843-969): single-positive and multi-positive batch dicts, uint8
+    frames kept as bytes, right-padding trimmed to the batch's longest text in buckets of 16."""
+    import numpy as np
+    import torch
+
+    from deepcoro_clip_amd.collate import custom_collate_fn, trim_padding
+
+    def enc(n, S=64):
+        ids = torch.zeros(S, dtype=torch.int64)
+        ids[:n] = torch.arange(1, n + 1)
+        m = torch.zeros(S, dtype=torch.int64)
+        m[:n] = 1
+        return {"input_ids": ids, "attention_mask": m}
+
+    vids = [np.random.default_rng(i).standard_normal((4, 8, 8, 3)).astype(np.float64) for i in range(3)]
+    single = [(vids[i], enc(5 + 9 * i), f"p{i}", f"report {i}") for i in range(3)]
+    out = custom_collate_fn(single)
+    assert set(out) == {"videos", "encoded_texts", "paths", "reports"}
+    assert out["videos"].shape == (3, 4, 8, 8, 3) and out["videos"].dtype == torch.float32
+    assert out["encoded_texts"]["input_ids"].shape == (3, 64) and out["paths"] == ["p0", "p1", "p2"]
+    trimmed = custom_collate_fn(single, trim_text_padding=True)
+    assert trimmed["encoded_texts"]["input_ids"].shape == (3, 32)  # longest = 23 tokens -> bucket of 32
+    assert torch.equal(trimmed["encoded_texts"]["attention_mask"].sum(1), out["encoded_texts"]["attention_mask"].sum(1))
+    ids, m = trim_padding(out["encoded_texts"]["input_ids"], out["encoded_texts"]["attention_mask"], bucket=8)
+    assert ids.shape == (3, 24)
+    # uint8 frames stay bytes (normalised on the GPU by the runner), multi-video studies keep their [N, T, H, W, C] block
+    u8 = [(np.zeros((2, 4, 8, 8, 3), np.uint8), enc(3), "p", "r")] * 2
+    assert custom_collate_fn(u8)["videos"].dtype == torch.uint8 and custom_collate_fn(u8)["videos"].shape == (2, 2, 4, 8, 8, 3)
+    # no texts
+    assert custom_collate_fn([(vids[0], None, "p", "r")])["encoded_texts"] is None
+    # multi-positive: unique prompts become columns, mask / weights rows
+    def entry(tid, n, ew=1.0, sw=1.0, abn=False):
+        return {"text_id": tid, "encoding": enc(n), "prompt_text": f"prompt {tid}", "prompt_type": "t", "edge_weight": ew,
+                "soft_weight": sw, "is_abnormal": abn, "tags": None}
+
+    batch = [(vids[0], {"positive_entries": [entry("a", 4, 2.0, 0.5), entry("b", 6)]}, "p0", "raw0"),
+             (vids[1], {"positive_entries": [entry("b", 6), entry("c", 9, 3.0, 1.0, True)]}, "p1", "raw1"),
+             (vids[2], {"positive_entries": []}, "p2", "raw2")]
+    mp = custom_collate_fn(batch, trim_text_padding=True)
+    assert mp["encoded_texts"]["input_ids"].shape == (3, 16) and mp["text_ids"] == ["a", "b", "c"]
+    assert mp["positive_mask"].tolist() == [[1, 1, 0], [0, 1, 1], [0, 0, 0]]
+    assert mp["positive_weights"].tolist() == [[1.0, 1.0, 0.0], [0.0, 1.0, 3.0], [0.0, 0.0, 0.0]]
+    assert [m_["is_abnormal"] for m_ in mp["text_metadata"]] == [False, False, True]
+    assert mp["reports"] == ["prompt a", "prompt b", "raw2"]
+    assert set(mp) == {"videos", "encoded_texts", "positive_mask", "positive_weights", "text_ids", "text_metadata", "paths", "reports"}
