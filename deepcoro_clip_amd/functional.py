@@ -793,6 +793,87 @@ def prepend_token(token, x):
     return PrependTokenFn.apply(token, x)
 
 
+class GateFn(torch.autograd.Function):
+    """tanh(v) * sigmoid(u): gated-attention features of the MIL head."""
+
+    @staticmethod
+    def forward(ctx, v, u):
+        v, u = _c(v), _c(u)
+        ctx.save_for_backward(v, u)
+        return K.gate_fwd(v, u)
+
+    @staticmethod
+    def backward(ctx, d):
+        v, u = ctx.saved_tensors
+        return K.gate_bwd(_c(d), v, u)
+
+
+class MaskedSoftmaxFn(torch.autograd.Function):
+    """softmax over dim 1 of fp32 scores [B, N] restricted to mask != 0 (uint8 [B, N] or None)."""
+
+    @staticmethod
+    def forward(ctx, s, mask):
+        w = K.masked_softmax_fwd(_c(s), mask)
+        ctx.save_for_backward(w)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        (w,) = ctx.saved_tensors
+        return K.masked_softmax_bwd(w, _c(dw)), None
+
+
+class WeightedSumFn(torch.autograd.Function):
+    """sum_n w[b, n] x[b, n, :]."""
+
+    @staticmethod
+    def forward(ctx, w, x):
+        w, x = _c(w), _c(x)
+        ctx.save_for_backward(w, x)
+        return K.wsum_fwd(w, x)
+
+    @staticmethod
+    def backward(ctx, d):
+        w, x = ctx.saved_tensors
+        dx, dw = K.wsum_bwd(w, x, _c(d))
+        return dw, dx
+
+
+class MaskedReduceFn(torch.autograd.Function):
+    """masked mean (mode 0) / masked max (mode 1) over dim 1 of [B, N, D]."""
+
+    @staticmethod
+    def forward(ctx, x, mask, mode):
+        x = _c(x)
+        out, arg = K.masked_reduce_fwd(x, mask, mode)
+        ctx.mask, ctx.arg, ctx.N, ctx.mode = mask, arg, x.shape[1], mode
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return K.masked_reduce_bwd(_c(d), ctx.mask, ctx.arg, ctx.N, ctx.mode), None, None
+
+
+def gate(v, u):
+    return GateFn.apply(v, u)
+
+
+def masked_softmax(s, mask=None):
+    return MaskedSoftmaxFn.apply(s, mask)
+
+
+def weighted_sum(w, x):
+    return WeightedSumFn.apply(w, x)
+
+
+def masked_mean(x, mask=None):
+    return MaskedReduceFn.apply(x, mask, 0)
+
+
+def masked_max(x, mask=None):
+    return MaskedReduceFn.apply(x, mask, 1)
+
+
 class StochasticDepthFn(torch.autograd.Function):
     """out = resid + branch * scale[sample]  (torchvision StochasticDepth, mode "row", fused with the residual add)."""
 
@@ -938,7 +1019,7 @@ def embed(ids, word, pos, typ, dtype):
 
 # ------------------------------------------------------------------- nn.MultiheadAttention core
 def multihead_attention(query, key_value, in_w, in_b, out_w, out_b, num_heads: int, self_attn: bool,
-                        dropout_p: float = 0.0, training: bool = False):
+                        dropout_p: float = 0.0, training: bool = False, kbias=None):
     """batch_first nn.MultiheadAttention forward (no masks) built from our GEMM + attention; `dropout_p` is the module's
     attention-weight dropout (applied to the softmax output in training mode, inside the flash kernels).
 
@@ -955,5 +1036,6 @@ def multihead_attention(query, key_value, in_w, in_b, out_w, out_b, num_heads: i
         q = linear(query, in_w[:E], in_b[:E]).view(B, Lq, num_heads, hd)
         kv = linear(key_value, in_w[E:], in_b[E:]).view(B, Lk, 2, num_heads, hd)
         k, v = kv[:, :, 0], kv[:, :, 1]
-    ctx = attention(q, k, v, 1.0 / math.sqrt(hd), dropout_p=dropout_p, training=training)
+    # kbias: additive fp32 [B, Lk] key bias (key_padding_mask as 0 / -1e30)
+    ctx = attention(q, k, v, 1.0 / math.sqrt(hd), kbias, dropout_p=dropout_p, training=training)
     return linear(ctx.reshape(B, Lq, E), out_w, out_b)

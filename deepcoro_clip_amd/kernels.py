@@ -805,3 +805,71 @@ def relu(x: torch.Tensor, gate: torch.Tensor | None = None) -> torch.Tensor:
     out = torch.empty_like(x)
     L.call("dcc_relu", L.ptr(x), L.ptr(gate), L.ptr(out), x.numel(), L.dt(x), L.stream())
     return out
+
+
+# ------------------------------------------------------------------------- multi-instance pooling
+def gate_fwd(v, u):
+    L.require_cuda(v, u)
+    assert v.is_contiguous() and u.is_contiguous() and v.shape == u.shape and v.dtype == u.dtype
+    out = torch.empty_like(v)
+    L.call("dcc_gate_fwd", L.ptr(v), L.ptr(u), L.ptr(out), v.numel(), L.dt(v), L.stream())
+    return out
+
+
+def gate_bwd(d, v, u):
+    L.require_cuda(d, v, u)
+    dv, du = torch.empty_like(v), torch.empty_like(u)
+    L.call("dcc_gate_bwd", L.ptr(d.contiguous()), L.ptr(v), L.ptr(u), L.ptr(dv), L.ptr(du), v.numel(), L.dt(v), L.stream())
+    return dv, du
+
+
+def masked_softmax_fwd(s, mask):
+    L.require_cuda(s, mask)
+    B, N = s.shape
+    assert s.dtype == torch.float32 and s.is_contiguous() and (mask is None or (mask.dtype == torch.uint8 and mask.shape == (B, N) and mask.is_contiguous()))
+    w = torch.empty_like(s)
+    L.call("dcc_masked_softmax_fwd", L.ptr(s), L.ptr(mask), L.ptr(w), B, N, L.stream())
+    return w
+
+
+def masked_softmax_bwd(w, dw):
+    L.require_cuda(w, dw)
+    ds = torch.empty_like(w)
+    L.call("dcc_masked_softmax_bwd", L.ptr(w), L.ptr(dw.contiguous()), L.ptr(ds), w.shape[0], w.shape[1], L.stream())
+    return ds
+
+
+def wsum_fwd(w, x):
+    L.require_cuda(w, x)
+    B, N, D = x.shape
+    assert w.shape == (B, N) and w.dtype == torch.float32 and w.is_contiguous() and x.is_contiguous()
+    out = torch.empty((B, D), device=x.device, dtype=x.dtype)
+    L.call("dcc_wsum_fwd", L.ptr(w), L.ptr(x), L.ptr(out), B, N, D, L.dt(x), L.stream())
+    return out
+
+
+def wsum_bwd(w, x, dout):
+    L.require_cuda(w, x, dout)
+    B, N, D = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    L.call("dcc_wsum_bwd", L.ptr(w), L.ptr(x), L.ptr(dout.contiguous()), L.ptr(dx), L.ptr(dw), B, N, D, L.dt(x), L.stream())
+    return dx, dw
+
+
+def masked_reduce_fwd(x, mask, mode: int):
+    L.require_cuda(x, mask)
+    B, N, D = x.shape
+    assert x.is_contiguous() and (mask is None or (mask.dtype == torch.uint8 and mask.shape == (B, N) and mask.is_contiguous()))
+    out = torch.empty((B, D), device=x.device, dtype=x.dtype)
+    arg = torch.empty((B, D), device=x.device, dtype=torch.int32) if mode == 1 else None
+    L.call("dcc_masked_reduce_fwd", L.ptr(x), L.ptr(mask), L.ptr(out), L.ptr(arg), B, N, D, int(mode), L.dt(x), L.stream())
+    return out, arg
+
+
+def masked_reduce_bwd(dout, mask, arg, N: int, mode: int):
+    L.require_cuda(dout, mask, arg)
+    B, D = dout.shape
+    dx = torch.empty((B, N, D), device=dout.device, dtype=dout.dtype)
+    L.call("dcc_masked_reduce_bwd", L.ptr(dout.contiguous()), L.ptr(mask), L.ptr(arg), L.ptr(dx), B, N, D, int(mode), L.dt(dout), L.stream())
+    return dx

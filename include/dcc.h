@@ -182,6 +182,21 @@ int dcc_scale_by_dev(float* x, int64_t n, const float* coef, void* stream);
 /* ReLU of nn.TransformerEncoderLayer (models/attention_pool.py:139-147): gate NULL -> y = max(x, 0); else y = x * [gate > 0]. */
 int dcc_relu(const void* x, const void* gate, void* y, int64_t n, int dtype, void* stream);
 
+/* ---- multi-instance pooling (csrc/mil.hip): token-level consumers of the encoder, models/multi_instance_linear_probing.py
+ * :494-538 (gated attention features tanh(Vx) * sigmoid(Ux), masked softmax over instances, weighted instance sums, masked
+ * mean / max) and the patch pooling of utils/loss/multitask_loss.py:281.  mask: uint8 [B,N], non-zero = valid, nullable. */
+int dcc_gate_fwd(const void* v, const void* u, void* out, int64_t n, int dtype, void* stream);
+int dcc_gate_bwd(const void* d, const void* v, const void* u, void* dv, void* du, int64_t n, int dtype, void* stream);
+int dcc_masked_softmax_fwd(const float* s, const uint8_t* mask, float* w, int B, int N, void* stream);
+int dcc_masked_softmax_bwd(const float* w, const float* dw, float* ds, int B, int N, void* stream);
+int dcc_wsum_fwd(const float* w, const void* x, void* out, int B, int N, int D, int dtype, void* stream);
+int dcc_wsum_bwd(const float* w, const void* x, const void* dout, void* dx, float* dw, int B, int N, int D, int dtype,
+                 void* stream);
+int dcc_masked_reduce_fwd(const void* x, const uint8_t* mask, void* out, int* arg, int B, int N, int D, int mode, int dtype,
+                          void* stream);
+int dcc_masked_reduce_bwd(const void* dout, const uint8_t* mask, const int* arg, void* dx, int B, int N, int D, int mode,
+                          int dtype, void* stream);
+
 /* ---- contrastive losses (csrc/loss.hip); scal = fp32[8]
  * {0 loss, 1 dlog_temp, 2 dbias, 3 mean diag log-softmax, 4 mean diag cosine, 5 sum ||v||, 6 sum ||t||, 7 -} */
 int dcc_l2norm_fwd(const float* x, int64_t ldx, float* y, float* norms, int R, int D, float eps, float* norm_sum,

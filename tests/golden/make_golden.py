@@ -209,6 +209,36 @@ def pools2():
     np.savez_compressed(os.path.join(OUT, "pools2.npz"), apcls_x=np_(x), apcls_y=np_(y), keys=np.array(sorted(m.state_dict().keys())))
 
 
+MIL_CASES = [  # (name, ctor kwargs, 4-D input?)
+    ("mean", dict(pooling_mode="mean"), False), ("max", dict(pooling_mode="max"), False),
+    ("attention", dict(pooling_mode="attention"), False), ("cls", dict(pooling_mode="cls_token"), False),
+    ("cls_shared_pre", dict(pooling_mode="cls_token", separate_video_attention=False, normalization_strategy="pre_norm"), False),
+    ("mean_cls", dict(pooling_mode="mean+cls_token"), False), ("attn_cls", dict(pooling_mode="attention+cls_token"), False),
+    ("attention4d", dict(pooling_mode="attention"), True), ("cls4d", dict(pooling_mode="cls_token"), True),
+    ("mean4d", dict(pooling_mode="mean"), True),
+]
+
+
+def mil():
+    """models/multi_instance_linear_probing.py: every pooling mode on [3, 5, 64] instance embeddings with a ragged mask, and
+    the hierarchical modes on [3, 5, 7, 64] patch tokens; name-seeded weights."""
+    M = load_by_path("ref_mil", "models/multi_instance_linear_probing.py")
+    g = torch.Generator().manual_seed(13)
+    x3 = torch.randn(3, 5, 64, generator=g)
+    x4 = torch.randn(3, 5, 7, 64, generator=g)
+    mask = torch.tensor([[1, 1, 1, 1, 1], [1, 1, 0, 1, 0], [1, 0, 0, 0, 0]], dtype=torch.bool)
+    out = {"x3": np_(x3), "x4": np_(x4), "mask": np_(mask)}
+    import warnings
+    for name, kw, four in MIL_CASES:
+        m = init_by_name(M.MultiInstanceLinearProbing(64, {"a": 3, "b": 1}, **kw)).eval()
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y = m(x4 if four else x3, mask=mask)
+        out[f"{name}_a"], out[f"{name}_b"] = np_(y["a"]), np_(y["b"])
+        out[f"{name}_keys"] = np.array(sorted(m.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "mil.npz"), **out)
+
+
 def loss_zoo():
     """Remaining loss zoo: auto-balance / entropy-regularised contrastive.SigLIPLoss,
     siglip_pairwise.SiglipPairwiseFeatureLoss, multi_positive_infonce.MultiPositiveInfoNCELoss, and the runner's
@@ -286,7 +316,7 @@ def loss_zoo():
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (losses, rope, pools, bert, retrieval, loss_zoo, pools2):
+    for fn in (losses, rope, pools, bert, retrieval, loss_zoo, pools2, mil):
         if only and fn.__name__ not in only:
             continue
         fn()

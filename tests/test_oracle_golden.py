@@ -245,3 +245,25 @@ def test_attention_pool_with_cls_oracle_matches_reference():
     with torch.no_grad():
         y = m(torch.from_numpy(g["apcls_x"]))
     assert (y - torch.from_numpy(g["apcls_y"])).abs().max() < 2e-5
+
+
+def test_mil_oracle_matches_reference():
+    """tests/golden/mil.npz (models/multi_instance_linear_probing.py, name-seeded weights): every pooling mode incl. the
+    hierarchical 4-D paths, ragged instance mask."""
+    import os
+
+    import numpy as np
+    from oracle.mil import MILOracle
+    from oracle.model import init_by_name
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mil.npz"))
+    x3, x4, mask = torch.from_numpy(g["x3"]), torch.from_numpy(g["x4"]), torch.from_numpy(g["mask"])
+    from tests.golden.make_golden import MIL_CASES
+    for name, kw, four in MIL_CASES:
+        m = init_by_name(MILOracle(64, {"a": 3, "b": 1}, mode=kw["pooling_mode"], separate=kw.get("separate_video_attention", True),
+                                   strategy=kw.get("normalization_strategy", "post_norm"))).eval()
+        assert sorted(m.state_dict().keys()) == list(g[f"{name}_keys"]), name
+        with torch.no_grad():
+            y = m(x4 if four else x3, mask)
+        for h in ("a", "b"):
+            assert (y[h] - torch.from_numpy(g[f"{name}_{h}"])).abs().max() < 2e-5, (name, h)
