@@ -163,6 +163,8 @@ class VideoEncoderOracle(nn.Module):
         self.aggregator = AggregatorOracle(output_dim, num_heads, aggregator_depth)
         self.attention_pool = AttentionPoolOracle(output_dim, attention_pool_heads) if token_pooling_mode == "attention" else (
             AttentionPoolWithCLSOracle(output_dim, attention_pool_heads) if token_pooling_mode == "cls_token" else None)
+        if token_pooling_mode == "cls_token":  # allocated but never used, as in the reference (models/video_encoder.py:147-153)
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, 768))
         self._apply_aggregator, self._per_video_pool = aggregate_videos_tokens, per_video_pool
 
     def features(self, x):
