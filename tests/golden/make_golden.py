@@ -220,17 +220,17 @@ MIL_CASES = [  # (name, ctor kwargs, 4-D input?)
 
 
 def mil():
-    """models/multi_instance_linear_probing.py: every pooling mode on [3, 5, 64] instance embeddings with a ragged mask, and
-    the hierarchical modes on [3, 5, 7, 64] patch tokens; name-seeded weights."""
+    """models/multi_instance_linear_probing.py: every pooling mode on [3, 5, 512] instance embeddings with a ragged mask, and
+    the hierarchical modes on [3, 5, 7, 512] patch tokens; name-seeded weights."""
     M = load_by_path("ref_mil", "models/multi_instance_linear_probing.py")
     g = torch.Generator().manual_seed(13)
-    x3 = torch.randn(3, 5, 64, generator=g)
-    x4 = torch.randn(3, 5, 7, 64, generator=g)
+    x3 = torch.randn(3, 5, 512, generator=g)
+    x4 = torch.randn(3, 5, 7, 512, generator=g)
     mask = torch.tensor([[1, 1, 1, 1, 1], [1, 1, 0, 1, 0], [1, 0, 0, 0, 0]], dtype=torch.bool)
     out = {"x3": np_(x3), "x4": np_(x4), "mask": np_(mask)}
     import warnings
     for name, kw, four in MIL_CASES:
-        m = init_by_name(M.MultiInstanceLinearProbing(64, {"a": 3, "b": 1}, **kw)).eval()
+        m = init_by_name(M.MultiInstanceLinearProbing(512, {"a": 3, "b": 1}, **kw)).eval()
         with torch.no_grad(), warnings.catch_warnings():
             warnings.simplefilter("ignore")
             y = m(x4 if four else x3, mask=mask)

@@ -27,9 +27,9 @@ def test_mil_matches_reference_golden_and_oracle_gradients(idx):
     g = np.load(os.path.join(G, "mil.npz"))
     x = torch.from_numpy(g["x4"] if four else g["x3"])
     mask = torch.from_numpy(g["mask"])
-    orc = init_by_name(MILOracle(64, {"a": 3, "b": 1}, mode=kw["pooling_mode"], separate=kw.get("separate_video_attention", True),
+    orc = init_by_name(MILOracle(512, {"a": 3, "b": 1}, mode=kw["pooling_mode"], separate=kw.get("separate_video_attention", True),
                                  strategy=kw.get("normalization_strategy", "post_norm"))).double()
-    m = MultiInstanceLinearProbing(64, {"a": 3, "b": 1}, **kw)
+    m = MultiInstanceLinearProbing(512, {"a": 3, "b": 1}, **kw)
     assert sorted(m.state_dict().keys()) == list(g[f"{name}_keys"])
     m.load_state_dict({k: v.float() for k, v in orc.state_dict().items()})
     m = m.cuda().eval()
@@ -48,10 +48,13 @@ def test_mil_matches_reference_golden_and_oracle_gradients(idx):
     rel = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm().clamp_min(1e-9))  # noqa: E731
     assert rel(xg.grad, xo.grad) < 1e-3, (name, rel(xg.grad, xo.grad))
     op = dict(orc.named_parameters())
+    norms = sorted(float(q.grad.norm()) for q in op.values() if q.grad is not None)
+    floor = 1e-3 * norms[len(norms) // 2]  # attention_w.bias shifts every score of a softmax alike: its gradient is exactly 0
     for n, p in m.named_parameters():
         if op[n].grad is None:
             continue
-        assert p.grad is not None and rel(p.grad, op[n].grad) < 2e-3, (name, n, rel(p.grad, op[n].grad))
+        err = float((p.grad.detach().cpu().double() - op[n].grad).norm() / op[n].grad.norm().clamp_min(floor))
+        assert p.grad is not None and err < 2e-3, (name, n, err)
 
 
 def test_mil_edge_cases_and_errors():

@@ -260,7 +260,7 @@ def test_mil_oracle_matches_reference():
     x3, x4, mask = torch.from_numpy(g["x3"]), torch.from_numpy(g["x4"]), torch.from_numpy(g["mask"])
     from tests.golden.make_golden import MIL_CASES
     for name, kw, four in MIL_CASES:
-        m = init_by_name(MILOracle(64, {"a": 3, "b": 1}, mode=kw["pooling_mode"], separate=kw.get("separate_video_attention", True),
+        m = init_by_name(MILOracle(512, {"a": 3, "b": 1}, mode=kw["pooling_mode"], separate=kw.get("separate_video_attention", True),
                                    strategy=kw.get("normalization_strategy", "post_norm"))).eval()
         assert sorted(m.state_dict().keys()) == list(g[f"{name}_keys"]), name
         with torch.no_grad():
