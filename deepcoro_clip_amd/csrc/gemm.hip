@@ -608,6 +608,15 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
     const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, variant == 8 ? 256 : 128, st);
     if (rc != DCC_ERR_UNSUPPORTED) return rc;
   }
+  // Measured on MI355X (tools/gemm_bench.py, profiles/r02_gemm_bench.txt): forward GEMMs with a short reduction and a
+  // wide output (fc1: N = 4C, qkv: N = 3C; K = C <= 768) run 12-15 % faster on 256 x 256 tiles with 8 unspecialised
+  // waves (half the L2 -> LDS operand traffic per FLOP) than on the ring kernel's 128 x 128 tiles; N = C outputs, k-major
+  // operands and deep reductions stay on the ring kernels (variant 10 disables this choice).
+  if (in_dtype == DCC_BF16 && out_dtype == DCC_BF16 && aligned && variant == 0 && !a_km && !b_km && batch == 1 && splitk == 1 &&
+      !(flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && N >= 1024 && M >= 8192 && K >= 128 && K <= 768) {
+    const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, 256, st);
+    if (rc != DCC_ERR_UNSUPPORTED) return rc;
+  }
   if (in_dtype == DCC_BF16 && aligned && variant != 3 && variant != 2 && !(small && variant == 6)) {
     const int rc = dcc_gemm_ring_launch(p, a_km, b_km, out_dtype, st);
     if (rc != DCC_ERR_UNSUPPORTED) return rc;

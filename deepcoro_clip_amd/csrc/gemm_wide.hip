@@ -6,8 +6,9 @@
 // pace.  A 256 x 256 tile halves the operand bytes per FLOP and the LDS fragment bytes per MFMA (a wave owns 128 x 64:
 // 24 fragment reads per 32 MFMAs instead of 16 per 16), and with two MFMA waves per SIMD one wave's LDS / barrier stalls
 // are covered by its partner instead of by dedicated loader waves.
-//   * operands: global -> LDS by LDS-DMA (16 B per lane, zero-fill through the buffer descriptor), two stages of one
-//     64-deep K-tile, every wave issues its share (8 KB) of a stage; counted vmcnt, raw barriers (2 per K-tile);
+//   * operands: global -> LDS by LDS-DMA (16 B per lane, zero-fill through the buffer descriptor) into a ring of four
+//     32-deep stages that runs three steps ahead; every wave issues its share of a stage (3-4 KB) BETWEEN its MFMAs of
+//     the current step; counted vmcnt, one raw barrier per step;
 //   * LDS images are stacks of 128-wide sub-tiles in the ring kernel's two layouts (k-contiguous rows with the chunk
 //     XOR-swizzled by the row, k-major rows read with ds_read_tr16_b64), so NN / NT / TN / TT are one kernel;
 //   * fp32 output (weight gradients): split-K over workgroups + fp32 atomics, the Linear layer's bias gradient
@@ -20,18 +21,21 @@
 namespace {
 
 constexpr int WNT = 512;
-constexpr int WBM = 256, WBK = 64;
-constexpr int SUB_B = 128 * WBK * 2;  // one 128-wide sub-tile of a stage (16 KB)
+constexpr int WBM = 256, WBK = 32;     // K elements per ring stage
+constexpr int WNS = 4, WD = WNS - 1;   // stages / steps in flight
+constexpr int SUB_B = 128 * WBK * 2;   // one 128-wide sub-tile of a stage (8 KB)
 
 __device__ __forceinline__ int wswz_km128(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
 template <int N> __device__ __forceinline__ void wwait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// 16 k of the 32 rows starting at t0 (< 128) of a k-contiguous sub-tile [128][64] bf16
+// 16 k of the 32 rows starting at t0 (< 128) of a k-contiguous sub-tile [128][32] bf16: 64-byte rows, the 16-byte chunk c
+// of row r stored at c ^ ((r >> 2) & 3) (four rows share a 256-byte bank row; the 16-lane groups of ds_read_b128 then
+// touch 16 different slots)
 __device__ __forceinline__ bf16x8 wfrag_kc(const char* sub, int t0, int s, int lane) {
   const int row = t0 + (lane & 31), chunk = 2 * s + (lane >> 5);
-  return *reinterpret_cast<const bf16x8*>(sub + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+  return *reinterpret_cast<const bf16x8*>(sub + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
 }
-// k-major sub-tile [64 k][128] bf16, transposing reads
+// k-major sub-tile [32 k][128] bf16 (256-byte rows), transposing reads
 __device__ __forceinline__ bf16x8 wfrag_km(const char* sub, int t0, int s, int lane) {
   const int h = lane >> 5, i = lane & 15, q = i >> 2, pp = i & 3, g = (lane >> 4) & 1;
   bf16x8 f;
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(WNT, 2) void gemm_wide_kernel(GemmParams p, WGeo ge
   constexpr int WM = BN == 256 ? 2 : 4, WN = 8 / WM;      // wave grid
   constexpr int RW = WBM / WM, CW = BN / WN;              // rows / columns of a wave's sub-tile (CW == 64)
   constexpr int TI = RW / 32, TJ = CW / 32;
-  constexpr int PPW = (NSA + NSB) * 16 / 8;               // 1-KB DMA pieces per wave per stage
+  constexpr int PPW = (NSA + NSB) * 8 / 8;                // 1-KB DMA pieces per wave per stage
   static_assert(CW == 64, "a wave owns 64 output columns");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -89,27 +93,24 @@ __global__ __launch_bounds__(WNT, 2) void gemm_wide_kernel(GemmParams p, WGeo ge
   int voff[PPW], kc[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
-    const int g = wave * PPW + j;                  // piece of the stage: A sub-tiles first, then B
-    const bool isA = g < NSA * 16;
-    const int gg = isA ? g : g - NSA * 16, sub = gg >> 4, pin = gg & 15;
+    const int g = wave * PPW + j;                  // piece of the stage: A sub-tiles first, then B (8 pieces of 1 KB each)
+    const bool isA = g < NSA * 8;
+    const int gg = isA ? g : g - NSA * 8, sub = gg >> 3, pin = gg & 7;
     const bool km = isA ? A_KM : B_KM;
     const int ld = (int)(isA ? p.lda : p.ldb);
     kc[j] = 0;
     if (km) { const int R = pin * 4 + (lane >> 4), c = (lane & 15) ^ wswz_km128(R); voff[j] = (R * ld + sub * 128 + c * 8) * 2; }
-    else { const int R = pin * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7); voff[j] = ((sub * 128 + R) * ld + c * 8) * 2; kc[j] = c * 8; }
+    else { const int R = pin * 16 + (lane >> 2), c = (lane & 3) ^ ((R >> 2) & 3); voff[j] = ((sub * 128 + R) * ld + c * 8) * 2; kc[j] = c * 8; }
   }
   const int kstrideA = A_KM ? WBK * (int)p.lda * 2 : WBK * 2, kstrideB = B_KM ? WBK * (int)p.ldb * 2 : WBK * 2;
-  auto issue = [&](int stage, int kb) {
-    char* st = smem + stage * STAGE;
-    const int k0 = kb * WBK;
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-      const int g = wave * PPW + j;
-      const bool isA = g < NSA * 16;
-      const bool km = isA ? A_KM : B_KM;
-      const int vo = (!km && k0 + kc[j] >= p.K) ? OOB : voff[j] + kb * (isA ? kstrideA : kstrideB);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, LDS_PTR(void, st + g * 1024), 16, vo, 0, 0, 0);
-    }
+  // `live` false: the step lies past this item's K range; the piece is still issued (out of range = zeros into a stage
+  // nobody reads) so that every step has the same number of loads in flight and the waits are compile-time constants
+  auto issue_piece = [&](int j, int stage, int kb, bool live) {
+    const int g = wave * PPW + j;
+    const bool isA = g < NSA * 8;
+    const bool km = isA ? A_KM : B_KM;
+    const int vo = (!live || (!km && kb * WBK + kc[j] >= p.K)) ? OOB : voff[j] + kb * (isA ? kstrideA : kstrideB);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, LDS_PTR(void, smem + stage * STAGE + g * 1024), 16, vo, 0, 0, 0);
   };
 
   // ---------------------------------------------------------------------------------------------- main loop
@@ -125,13 +126,18 @@ __global__ __launch_bounds__(WNT, 2) void gemm_wide_kernel(GemmParams p, WGeo ge
 #pragma unroll
   for (int i = 0; i < TI; ++i) csum[i] = 0.0f;
 
-  issue(0, ks0);
-  if (nk > 1) issue(1, ks0 + 1);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) wwait_vm<PPW>(); else wwait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    const char* sa = smem + (kt & 1) * STAGE;
+#pragma unroll
+  for (int d = 0; d < WD; ++d) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) issue_piece(j, d, ks0 + d, d < nk);
+  }
+  for (int q = 0; q < nk; ++q) {
+    wwait_vm<(WD - 1) * PPW>();    // this wave's pieces of step q have landed: only the two younger steps' may be out
+    __builtin_amdgcn_s_barrier();  // step q landed for everyone; everyone is done reading step q - 1's stage
+    const char* sa = smem + (q % WNS) * STAGE;
     const char* sb = sa + NSA * SUB_B;
+    const int nq = q + WD;          // the step whose loads go out underneath this step's MFMAs, into step q - 1's stage
+    const bool more = nq < nk;
     bf16x8 fa[2][TI], fb[2][TJ];
     auto fetch = [&](int buf, int s) {
 #pragma unroll
@@ -152,12 +158,17 @@ __global__ __launch_bounds__(WNT, 2) void gemm_wide_kernel(GemmParams p, WGeo ge
       if (s + 1 < WBK / 16) fetch(cur ^ 1, s + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+      for (int i = 0; i < TI; ++i) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
           if constexpr (OUT16) acc[i][j] = mma16(fb[cur][j], fa[cur][i], acc[i][j]);   // C^T: lanes = rows m
           else acc[i][j] = mma16(fa[cur][i], fb[cur][j], acc[i][j]);
         }
+        // one DMA piece behind every TJ MFMAs (the matrix pipe keeps draining while the wave issues it)
+        constexpr int STR = (2 * TI) / PPW >= 1 ? (2 * TI) / PPW : 1;   // spread the pieces over the step's MFMA groups
+        const int pos = s * TI + i;
+        if (pos % STR == 0 && pos / STR < PPW) issue_piece(pos / STR, nq % WNS, ks0 + nq, more);
+      }
       if (A_KM && do_colsum) {  // bias gradient: sum over k of this lane's 8 A elements (row = lane & 31 of tile i)
 #pragma unroll
         for (int i = 0; i < TI; ++i)
@@ -165,11 +176,9 @@ __global__ __launch_bounds__(WNT, 2) void gemm_wide_kernel(GemmParams p, WGeo ge
           for (int e = 0; e < 8; ++e) csum[i] += (float)fa[cur][i][e];
       }
     }
-    if (kt + 2 < nk) {
-      __builtin_amdgcn_s_barrier();          // every wave is done reading this stage
-      issue(kt & 1, ks0 + kt + 2);
-    }
   }
+
+  wwait_vm<0>();  // the trailing dummy pieces too: the epilogue reuses the stages
 
   // ------------------------------------------------------------------------------------------------ epilogue
   if (A_KM && do_colsum) {
@@ -276,7 +285,7 @@ int wide_launch(const GemmParams& p, const WGeo& geo, hipStream_t st) {
   constexpr int STAGE = (NSA + NSB) * SUB_B;
   constexpr int WM = BN == 256 ? 2 : 4;
   constexpr int STRIP = 8 * (WBM / WM) * (2 * 64 + 16);
-  constexpr int LDS = (2 * STAGE > STRIP) ? 2 * STAGE : STRIP;
+  constexpr int LDS = (WNS * STAGE > STRIP) ? WNS * STAGE : STRIP;
   auto kern = gemm_wide_kernel<TC, A_KM, B_KM, BN>;
   static bool configured = false;
   if (!configured) {

@@ -37,6 +37,17 @@ def bench(M, N, Kd, a_km=False, b_km=False, tag="", **kw):
 
 
 M = 50208
+VAR = int(os.environ.get("DCC_GEMM_VARIANT", "0"))
+
+
+def wsplit(rows, n, k):
+    if VAR in (8, 9):  # 256 x (256 | 128) tiles: about one item per CU
+        bn = 256 if VAR == 8 else 128
+        tiles = ((n + 255) // 256) * ((k + bn - 1) // bn)
+        return max(1, min(256 // tiles, rows // 256))
+    return K.wgrad_splitk(rows, n, k)
+
+
 bench(M, 1536, 384, tag="fc1 fwd bias+gelu+pre", bias=True, gelu=True, save_pre=True)
 bench(M, 384, 1536, tag="fc2 fwd bias+resid", bias=True, resid=True)
 bench(M, 1152, 384, tag="qkv fwd bias", bias=True)
@@ -45,9 +56,9 @@ bench(M, 1536, 384, b_km=True, tag="dpre = dy W2 * gelu'", dgelu=True)
 bench(M, 384, 1536, b_km=True, tag="dx = dpre W1")
 bench(M, 384, 1152, b_km=True, tag="dx = dqkv Wqkv")
 bench(M, 1536, 384, tag="plain K384")
-bench(1536, 384, M, a_km=True, b_km=True, tag="wgrad fc2", out_dtype=torch.float32, splitk=K.wgrad_splitk(M, 1536, 384))
-bench(384, 1536, M, a_km=True, b_km=True, tag="wgrad fc1", out_dtype=torch.float32, splitk=K.wgrad_splitk(M, 384, 1536))
-bench(1152, 384, M, a_km=True, b_km=True, tag="wgrad qkv", out_dtype=torch.float32, splitk=K.wgrad_splitk(M, 1152, 384))
+bench(1536, 384, M, a_km=True, b_km=True, tag="wgrad fc2", out_dtype=torch.float32, splitk=wsplit(M, 1536, 384))
+bench(384, 1536, M, a_km=True, b_km=True, tag="wgrad fc1", out_dtype=torch.float32, splitk=wsplit(M, 384, 1536))
+bench(1152, 384, M, a_km=True, b_km=True, tag="wgrad qkv", out_dtype=torch.float32, splitk=wsplit(M, 1152, 384))
 bench(200832, 576, 192, tag="blk2 qkv", bias=True)
 bench(802848, 288, 96, tag="blk0 qkv", bias=True)
 bench(8192, 8192, 8192, tag="8192^3")
