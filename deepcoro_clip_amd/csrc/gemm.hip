@@ -15,6 +15,7 @@
 #include "common.h"
 
 #include "gemm_params.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -612,10 +613,18 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   // wide output (fc1: N = 4C, qkv: N = 3C; K = C <= 768) run 12-15 % faster on 256 x 256 tiles with 8 unspecialised
   // waves (half the L2 -> LDS operand traffic per FLOP) than on the ring kernel's 128 x 128 tiles; N = C outputs, k-major
   // operands and deep reductions stay on the ring kernels (variant 10 disables this choice).
-  if (in_dtype == DCC_BF16 && out_dtype == DCC_BF16 && aligned && variant == 0 && !a_km && !b_km && batch == 1 && splitk == 1 &&
-      !(flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && N >= 1024 && M >= 8192 && K >= 128 && K <= 768) {
-    const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, 256, st);
-    if (rc != DCC_ERR_UNSUPPORTED) return rc;
+  static const int wide_mode = getenv("DCC_WIDE_MODE") ? atoi(getenv("DCC_WIDE_MODE")) : 0;  // experiments: 1-3 widen the choice
+  if (in_dtype == DCC_BF16 && out_dtype == DCC_BF16 && aligned && variant == 0 && !a_km && batch == 1 && splitk == 1 &&
+      !(flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && M >= 8192 && K >= 128) {
+    int bn = 0;
+    if (!b_km && N >= 1024 && K <= 768) bn = 256;
+    if (wide_mode >= 1 && b_km && N >= 1024 && K <= 768) bn = 256;            // dgelu / NT with a wide output
+    if (wide_mode >= 2 && N >= 256 && N < 1024) bn = (N % 256 == 0) ? 256 : 128;  // N = C outputs
+    if (wide_mode >= 3 && bn == 0 && N >= 1024) bn = 256;                      // deep K too
+    if (bn) {
+      const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, bn, st);
+      if (rc != DCC_ERR_UNSUPPORTED) return rc;
+    }
   }
   if (in_dtype == DCC_BF16 && aligned && variant != 3 && variant != 2 && !(small && variant == 6)) {
     const int rc = dcc_gemm_ring_launch(p, a_km, b_km, out_dtype, st);

@@ -32,4 +32,6 @@ print(json.dumps(rec))
 for name, agg in (("FETCH_SIZE", f), ("WRITE_SIZE", w)):
     print(f"--- {name} by kernel family (KB)")
     for fam, (c, v) in sorted(agg.items(), key=lambda x: -x[1][1])[:14]:
+        if c == 0:
+            continue
         print(f"{fam:60s} launches {c:6d} total {v:.4g} per-launch {v / c:.4g}")

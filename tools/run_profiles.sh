@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o ${TAG} -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-roofline > $R/gpurun_out/${TAG}_prof.log 2>&1 || exit 2
 python $R/tools/prof_summary.py $R/gpurun_out/${TAG}_prof 15 80 > $R/gpurun_out/${TAG}_per_grid_summary.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/${TAG}_pmc_$C -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1 || exit 3
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/${TAG}_pmc_$C -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1 || exit 3
 done
 python $R/tools/pmc_traffic.py $R/gpurun_out/${TAG}_pmc_FETCH_SIZE $R/gpurun_out/${TAG}_pmc_WRITE_SIZE $R/gpurun_out/${TAG}_pmc_gemm_traffic.json bf16 8 4 16 224 attention > $R/gpurun_out/${TAG}_pmc_summary.txt 2>&1
 head -3 $R/gpurun_out/${TAG}_pmc_summary.txt
