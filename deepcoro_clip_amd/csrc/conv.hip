@@ -424,6 +424,36 @@ template <typename TD> __device__ __forceinline__ __amdgpu_buffer_rsrc_t span_rs
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<TD*>(p), 0, (int)bytes, 0x00020000);
 }
 
+// Hardware block b runs on XCD b % 8.  This logical order gives every XCD a CONTIGUOUS range of the grid, so the rows and
+// frames that neighbouring runs share are fetched into one L2 instead of all eight (PMC: L2 misses of the stride-1 pool
+// were 4.8x its input with the round-robin order).
+__device__ __forceinline__ unsigned xcd_block() {
+  const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, qb = nb >> 3, rb = nb & 7;
+  return xcd * qb + (xcd < rb ? xcd : rb) + (blockIdx.x >> 3);
+}
+// w [C][27] fp32 -> LDS [27][C] (MIRROR: taps reversed).  Coalesced reads, eight in flight per thread: the first version
+// (one strided load, wait, one LDS store per iteration) cost every block ten dependent L2 round trips before its first
+// stencil load.
+template <bool MIRROR> __device__ __forceinline__ void stage_w27(float* wl, const float* __restrict__ w, int C) {
+  const int n = 27 * C;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u;
+      v[u] = i < n ? w[i] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u;
+      if (i < n) {
+        const int c = i / 27, k = i - c * 27;
+        wl[(MIRROR ? 26 - k : k) * C + c] = v[u];
+      }
+    }
+  }
+}
+
 // raw (unconverted) CV-element vector: issue all loads of a phase first, convert when consumed
 template <typename TD, int CV> struct RawCV { f32x4 q[sizeof(TD) * CV / 16]; };
 template <typename TD, int CV> __device__ __forceinline__ RawCV<TD, CV> load_raw(const TD* p) {
@@ -500,15 +530,12 @@ __global__ __launch_bounds__(256) void dw3_run_kernel(const TD* __restrict__ x, 
   constexpr int SEG = (WT - 1) * S + 3;
   extern __shared__ __attribute__((aligned(16))) float wl3[];  // [27][C]
   const PoolGeom& g = r.g;
-  for (int i = threadIdx.x; i < 27 * g.C; i += 256) {
-    const int k = i / g.C, c = i - k * g.C;
-    wl3[i] = w[c * 27 + (MIRROR ? 26 - k : k)];
-  }
+  stage_w27<MIRROR>(wl3, w, g.C);
   __syncthreads();
   const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
   const int c = threadIdx.x - rs * r.cpr;
   if ((int)rs >= r.slots) return;
-  const unsigned run = blockIdx.x * r.slots + rs;
+  const unsigned run = xcd_block() * r.slots + rs;
   if ((int)run >= r.runs) {  // class tokens bypass the pooling
     const int i = run - r.runs;
     if (g.has_cls && i < g.B * g.H) {
@@ -586,6 +613,209 @@ __global__ __launch_bounds__(256) void dw3_run_kernel(const TD* __restrict__ x, 
   }
 }
 
+// =====================================================================================================
+// Fused q/k/v pool: depthwise 3x3x3 conv + the per-head LayerNorm(96) that follows it (torchvision mvit.Pool =
+// conv -> norm), bf16, head_dim 96.  One launch instead of two, the conv output is not read back from HBM, and the
+// thread mapping is chosen for the LayerNorm: a 16-lane DPP row owns one run of WT output columns with 6 channels
+// (12 bytes) per lane, so the row statistics are four v_add_dpp steps and no lane idles (the stand-alone LayerNorm
+// kernel packs a 96-wide row into 12 of 16 lanes).  One accumulator set per thread (WT x 6) and a two-row ring of raw
+// loads keep the kernel at 3-4 waves per SIMD; the run kernel above holds a 27-load slab and 56 accumulators (2 waves).
+// Outputs: y = conv rounded to bf16 (saved for the LayerNorm backward), o = LayerNorm(y) with its own row stride (the
+// [.., DQK] attention operand), mean / rstd per row.  The class token bypasses the conv and is normalised like any row.
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));   // register triple of the 12-byte buffer loads only:
+struct alignas(4) Raw6 { unsigned q[3]; };                     // memory accesses go through this 12-byte, 4-aligned type
+__device__ __forceinline__ Raw6 raw6_load_buf(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0);
+  return Raw6{{v[0], v[1], v[2]}};
+}
+
+__device__ __forceinline__ float row16_sum(float s) {  // all-reduce over the 16 lanes of a DPP row
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x128, 0xf, 0xf, false));
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x124, 0xf, 0xf, false));
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x122, 0xf, 0xf, false));
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x121, 0xf, 0xf, false));
+  return s;
+}
+__device__ __forceinline__ void raw6_to_f32(const Raw6& r, float* f) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    f[2 * i] = __builtin_bit_cast(float, r.q[i] << 16);
+    f[2 * i + 1] = __builtin_bit_cast(float, r.q[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ Raw6 f32_to_raw6(const float* f) {
+  Raw6 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const bf16x2 t = {(bf16_t)f[2 * i], (bf16_t)f[2 * i + 1]};
+    r.q[i] = __builtin_bit_cast(unsigned, t);
+  }
+  return r;
+}
+
+// one row of 96 (6 per lane, v = the bf16-rounded conv output): statistics as norm.hip (two-pass, fp32), store o / mean / rstd
+__device__ __forceinline__ void ln96_row_store(const float* v, const float* gam, const float* bet, float eps, bf16_t* orow,
+                                               float* mean, float* rstd, int64_t row, bool lane0) {
+  float s = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) s += v[e];
+  const float mu = row16_sum(s) * (1.0f / 96.0f);
+  float q = 0.0f, d[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) { d[e] = v[e] - mu; q += d[e] * d[e]; }
+  const float rs = rsqrtf(row16_sum(q) * (1.0f / 96.0f) + eps);
+  float out[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) out[e] = d[e] * rs * gam[e] + bet[e];
+  *reinterpret_cast<Raw6*>(orow) = f32_to_raw6(out);
+  if (lane0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <int S, int WT, int PD>
+__global__ __launch_bounds__(256, PD == 0 ? 4 : 2) void dw3_ln_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, bf16_t* __restrict__ o,
+                                                     int64_t ldo, const float* __restrict__ w, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, float eps, RunGeom r) {
+  constexpr int NC = (WT - 1) * S + 3;
+  __shared__ f32x4 wA[27 * 16];   // channels 6l .. 6l+3 of tap k at [k * 16 + l]
+  __shared__ f32x2 wB[27 * 16];   // channels 6l+4, 6l+5
+  __shared__ float gbs[2 * 96];
+  const PoolGeom& g = r.g;
+  {  // weights [96][27] -> the LDS images: coalesced loads, all in flight together (a load-wait-store loop costs a block
+     // ten dependent L2 round trips before its first stencil load)
+    float wv[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      wv[i] = idx < 27 * 96 ? w[idx] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int c = idx / 27, k = idx - c * 27, lc = c / 6, e = c - lc * 6;
+      if (idx < 27 * 96) {
+        if (e < 4) reinterpret_cast<float*>(wA)[(k * 16 + lc) * 4 + e] = wv[i];
+        else reinterpret_cast<float*>(wB)[(k * 16 + lc) * 2 + (e - 4)] = wv[i];
+      }
+    }
+  }
+  if (threadIdx.x < 96) gbs[threadIdx.x] = gamma[threadIdx.x];
+  else if (threadIdx.x < 192) gbs[threadIdx.x] = beta[threadIdx.x - 96];
+  __syncthreads();
+  const int l = threadIdx.x & 15;
+  const unsigned run = xcd_block() * 16 + (threadIdx.x >> 4);
+  float gam[6], bet[6];
+  const int No = g.To * g.Ho * g.Wo + g.has_cls;
+  if ((int)run >= r.runs) {  // class tokens: no conv, same LayerNorm
+    const int i = run - r.runs;
+    if (g.has_cls && i < g.B * g.H) {
+      const int b = i / g.H, hd = i - b * g.H;
+      const Raw6 q = *reinterpret_cast<const Raw6*>(x + b * g.sxb + hd * g.sxh + l * 6);
+      float v[6];
+      raw6_to_f32(q, v);
+      *reinterpret_cast<Raw6*>(y + b * g.syb + hd * g.syh + l * 6) = q;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) { gam[e] = gbs[l * 6 + e]; bet[e] = gbs[96 + l * 6 + e]; }
+      const int64_t row = ((int64_t)b * No) * g.H + hd;
+      ln96_row_store(v, gam, bet, eps, o + row * ldo + l * 6, mean, rstd, row, l == 0);
+    }
+    return;
+  }
+  const RunPos p = run_pos(run, r, WT);
+  const __amdgpu_buffer_rsrc_t rsx = span_rsrc(x, r.xspan);
+  const unsigned xbase = p.b * r.bxb + p.hd * r.bxh + l * 12u;
+  float acc[WT][6];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int e = 0; e < 6; ++e) acc[i][e] = 0.0f;
+  const int col0 = p.w0 * S - 1;
+  unsigned coff[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int col = col0 + j;
+    coff[j] = (col >= 0 && col < g.Ws) ? (unsigned)col * r.bxn : OOB;
+  }
+  // The 9 (kt, kh) input rows are walked in order by a ROLLED loop (unrolled, the compiler sinks all the arithmetic below
+  // all the loads and parks 80 loads in AGPRs); PD = 1: two row buffers, the next row's loads go out before the current
+  // row is consumed.  Out-of-range rows read zeros through the OOB offset, so the body has no branches.
+  auto issue = [&](int step, Raw6 (&buf)[NC]) {
+    const int kt = (step * 11) >> 5, kh = step - kt * 3;  // step / 3 for 0..8
+    const int t = p.to + kt - 1, hh = p.ho * S + kh - 1;
+    const bool ok = ((unsigned)t < (unsigned)g.T) & ((unsigned)hh < (unsigned)g.Hs);
+    const unsigned rowoff = xbase + (unsigned)(g.has_cls + (t * g.Hs + hh) * g.Ws) * r.bxn;
+    const unsigned row = ok ? rowoff : OOB;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      if (S > 2 && (j % S) > 2) continue;  // columns between the windows of a wide stride are never used
+      buf[j] = raw6_load_buf(rsx, sat_add(row, coff[j]));
+    }
+  };
+  auto consume = [&](int step, const Raw6 (&buf)[NC]) {
+    float wt[3][6];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const f32x4 a = wA[(step * 3 + kw) * 16 + l];
+      const f32x2 b = wB[(step * 3 + kw) * 16 + l];
+      wt[kw][0] = a[0]; wt[kw][1] = a[1]; wt[kw][2] = a[2]; wt[kw][3] = a[3]; wt[kw][4] = b[0]; wt[kw][5] = b[1];
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      if (S > 2 && (j % S) > 2) continue;
+      float f[6];
+      raw6_to_f32(buf[j], f);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        if ((j - kw) >= 0 && (j - kw) % S == 0 && (j - kw) / S < WT) {
+#pragma unroll
+          for (int e = 0; e < 6; ++e) acc[(j - kw) / S][e] += f[e] * wt[kw][e];
+        }
+      }
+    }
+  };
+  if constexpr (PD == 0) {
+    Raw6 A[NC];
+#pragma unroll 1
+    for (int step = 0; step < 9; ++step) {
+      issue(step, A);
+      consume(step, A);
+    }
+  } else {
+    Raw6 A[NC], Bf[NC];
+    issue(0, A);
+#pragma unroll 1
+    for (int s2 = 0; s2 < 8; s2 += 2) {
+      issue(s2 + 1, Bf);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(s2, A);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(s2 + 2, A);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(s2 + 1, Bf);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    consume(8, A);
+  }
+#pragma unroll
+  for (int e = 0; e < 6; ++e) { gam[e] = gbs[l * 6 + e]; bet[e] = gbs[96 + l * 6 + e]; }
+  const int n0 = g.has_cls + (p.to * g.Ho + p.ho) * g.Wo + p.w0;
+  bf16_t* yrow = y + p.b * g.syb + p.hd * g.syh + (int64_t)n0 * g.syn + l * 6;
+  int64_t row = ((int64_t)p.b * No + n0) * g.H + p.hd;
+  bf16_t* orow = o + row * ldo + l * 6;
+  const int64_t ostep = g.H * ldo;
+#pragma unroll
+  for (int i = 0; i < WT; ++i) {
+    if (p.w0 + i < g.Wo) {  // uniform over the 16 lanes of the run
+      const Raw6 q = f32_to_raw6(acc[i]);
+      *reinterpret_cast<Raw6*>(yrow) = q;
+      float v[6];
+      raw6_to_f32(q, v);
+      ln96_row_store(v, gam, bet, eps, orow, mean, rstd, row, l == 0);
+    }
+    yrow += g.syn; orow += ostep; row += g.H;
+  }
+}
+
 // data gradient of a strided pool (S >= 2): one thread per input position chunk, exact tap enumeration.
 // x-strides describe dx, y-strides dy (as dcc_pool_bwd_data).
 template <typename T, typename TD, int S>
@@ -594,15 +824,12 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_strided_kernel(const TD* __r
   constexpr int CV = Vec16<T>::N;
   extern __shared__ __attribute__((aligned(16))) float wl3[];
   const PoolGeom& g = r.g;
-  for (int i = threadIdx.x; i < 27 * g.C; i += 256) {
-    const int k = i / g.C, c = i - k * g.C;
-    wl3[i] = w[c * 27 + k];
-  }
+  stage_w27<false>(wl3, w, g.C);
   __syncthreads();
   const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
   const int c = threadIdx.x - rs * r.cpr;
   if ((int)rs >= r.slots) return;
-  const unsigned id = blockIdx.x * r.slots + rs;  // position index over (b, head, t, h, w), then class tokens
+  const unsigned id = xcd_block() * r.slots + rs;  // position index over (b, head, t, h, w), then class tokens
   const int npos = g.B * g.H * g.T * g.Hs * g.Ws;
   float acc[CV];
 #pragma unroll
@@ -673,15 +900,12 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_s2_kernel(const TD* __restri
   constexpr int CV = Vec16<T>::N;
   extern __shared__ __attribute__((aligned(16))) float wl3[];  // [27][C]
   const PoolGeom& g = r.g;
-  for (int i = threadIdx.x; i < 27 * g.C; i += 256) {
-    const int k = i / g.C, c = i - k * g.C;
-    wl3[i] = w[c * 27 + k];
-  }
+  stage_w27<false>(wl3, w, g.C);
   __syncthreads();
   const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
   const int c = threadIdx.x - rs * r.cpr;
   if ((int)rs >= r.slots) return;
-  const unsigned run = blockIdx.x * r.slots + rs;
+  const unsigned run = xcd_block() * r.slots + rs;
   const int nruns = r.runs * 2;  // r.runs = B * H * To * Ho * runsW (one per output row run), two input rows each
   if ((int)run >= nruns) {
     const int i = run - nruns;
@@ -777,15 +1001,12 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_wide_kernel(const TD* __rest
   constexpr int CV = Vec16<T>::N;
   extern __shared__ __attribute__((aligned(16))) float wl3[];  // [27][C]
   const PoolGeom& g = r.g;
-  for (int i = threadIdx.x; i < 27 * g.C; i += 256) {
-    const int k = i / g.C, c = i - k * g.C;
-    wl3[i] = w[c * 27 + k];
-  }
+  stage_w27<false>(wl3, w, g.C);
   __syncthreads();
   const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
   const int c = threadIdx.x - rs * r.cpr;
   if ((int)rs >= r.slots) return;
-  const unsigned run = blockIdx.x * r.slots + rs;
+  const unsigned run = xcd_block() * r.slots + rs;
   const int nruns = g.B * g.H * g.T * g.Hs * r.runsW;
   if ((int)run >= nruns) {
     const int i = run - nruns;
@@ -878,7 +1099,7 @@ __global__ __launch_bounds__(256) void maxpool_s2_fwd_kernel(const T* __restrict
   const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
   const int c = threadIdx.x - rs * r.cpr;
   if ((int)rs >= r.slots) return;
-  const unsigned id = blockIdx.x * r.slots + rs;
+  const unsigned id = xcd_block() * r.slots + rs;
   const int npos = g.B * g.H * g.To * g.Ho * g.Wo;
   const int No = g.To * g.Ho * g.Wo + g.has_cls;
   if ((int)id >= npos) {
@@ -961,7 +1182,7 @@ __global__ __launch_bounds__(256) void maxpool_s2_bwd_kernel(const TD* __restric
   const unsigned rs = fdiv(threadIdx.x, r.d_cpr);
   const int c = threadIdx.x - rs * r.cpr;
   if ((int)rs >= r.slots) return;
-  const unsigned id = blockIdx.x * r.slots + rs;
+  const unsigned id = xcd_block() * r.slots + rs;
   const int npos = g.B * g.H * g.T * g.Hs * g.Ws;
   float acc[CV];
 #pragma unroll
@@ -1027,9 +1248,10 @@ __global__ __launch_bounds__(256) void dw3_wgrad_kernel(const TD* __restrict__ d
 #pragma unroll
     for (int e = 0; e < CV; ++e) acc[k][e] = 0.0f;
   const __amdgpu_buffer_rsrc_t rsx = span_rsrc(x, r.xspan), rsy = span_rsrc(dy, r.yspan);
+  const unsigned lblk = xcd_block();
   if ((int)slot < slots3 * 3) {
     for (int it = 0; it < iters; ++it) {
-      const unsigned run = (blockIdx.x * iters + it) * slots3 + rsl;
+      const unsigned run = (lblk * iters + it) * slots3 + rsl;
       if ((int)run >= r.runs) break;
       const RunPos p = run_pos(run, r, WT);
       const int t = p.to + kt - 1;
@@ -1117,9 +1339,10 @@ __global__ __launch_bounds__(256) void dw3_wgrad_march_kernel(const TD* __restri
 #pragma unroll
     for (int e = 0; e < CV; ++e) acc[k][e] = 0.0f;
   const __amdgpu_buffer_rsrc_t rsx = span_rsrc(x, r.xspan), rsy = span_rsrc(dy, r.yspan);
+  const unsigned lblk = xcd_block();
   if ((int)slot < slots3 * 3) {
     for (int it = 0; it < iters; ++it) {
-      const unsigned run = (blockIdx.x * iters + it) * slots3 + rsl;
+      const unsigned run = (lblk * iters + it) * slots3 + rsl;
       if ((int)run >= nruns) break;
       // run -> (b, head, ho, first output column)
       const unsigned t1 = fdiv(run, r.d_runsW);
@@ -1401,6 +1624,44 @@ extern "C" int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* arg
     if (mode == 0) hipLaunchKernelGGL((pool_fwd_kernel<float, false>), grid, dim3(256), lds, s, (const float*)x, (float*)y, w, argmax, g);
     else hipLaunchKernelGGL((pool_fwd_kernel<float, true>), grid, dim3(256), lds, s, (const float*)x, (float*)y, w, argmax, g);
   } else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+// Fused depthwise-conv pool + LayerNorm over the head dimension (bf16, C == 96, kernel 3x3x3 / padding 1 / temporal
+// stride 1 / spatial stride 1, 2, 4 or 8).  y: conv output [B,No,H,C] (y-strides), o: LayerNorm(y) rows [(b,n,h)] with row
+// stride ldo, mean / rstd fp32 per row.  DCC_ERR_UNSUPPORTED outside that domain (callers use dcc_pool_fwd + dcc_layernorm_fwd).
+extern "C" int dcc_pool_ln_fwd(const void* x, void* y, void* o, int64_t ldo, const float* w, const float* gamma,
+                               const float* beta, float* mean, float* rstd, const int* dims, const int64_t* strides, float eps,
+                               int dtype, void* stream) {
+  if (!x || !y || !o || !w || !gamma || !beta || !mean || !rstd || !dims || !strides) return DCC_ERR_ARG;
+  if (dtype != DCC_BF16) return DCC_ERR_UNSUPPORTED;
+  PoolGeom g = make_geom(dims, strides);
+  if (g.B <= 0 || g.H <= 0 || g.T <= 0 || g.Hs <= 0 || g.Ws <= 0) return DCC_ERR_ARG;
+  if (g.C != 96) return DCC_ERR_UNSUPPORTED;
+  const int S = dw3_stride(g, 2);
+  if (S == 0) return DCC_ERR_UNSUPPORTED;
+  const int64_t st[] = {g.sxb, g.sxn, g.sxh, g.syb, g.syn, g.syh, ldo};
+  for (int64_t v : st)
+    if (v % 2) return DCC_ERR_UNSUPPORTED;  // 4-byte aligned 12-byte accesses
+  if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)o)) & 3) return DCC_ERR_UNSUPPORTED;
+  const int WT = (S == 1 && g.Wo % 7 == 0) ? 7 : 4;
+  RunGeom r = make_run_geom(g, 6, WT);
+  if (!set_spans(r, 2, 2)) return DCC_ERR_UNSUPPORTED;
+  const int items = r.runs + (g.has_cls ? g.B * g.H : 0);
+  const dim3 grid((items + 15) / 16);
+  hipStream_t s = (hipStream_t)stream;
+  static const int pd = getenv("DCC_POOL_LN_PD") ? atoi(getenv("DCC_POOL_LN_PD")) : 1;  // A/B knob of tools/pool_bench.py
+#define POOL_LN(S_, WT_)                                                                                                        \
+  do {                                                                                                                          \
+    if (pd == 0) hipLaunchKernelGGL((dw3_ln_kernel<S_, WT_, 0>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)o, ldo, w, gamma, beta, mean, rstd, eps, r); \
+    else hipLaunchKernelGGL((dw3_ln_kernel<S_, WT_, 1>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)o, ldo, w, gamma, beta, mean, rstd, eps, r); \
+  } while (0)
+  if (S == 1 && WT == 7) POOL_LN(1, 7);
+  else if (S == 1) POOL_LN(1, 4);
+  else if (S == 2) POOL_LN(2, 4);
+  else if (S == 4) POOL_LN(4, 4);
+  else POOL_LN(8, 4);
+#undef POOL_LN
   return dcc_check_launch();
 }
 

@@ -7,6 +7,7 @@ masters with cached bf16 shadows, weight/bias gradients come back in fp32.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -485,6 +486,11 @@ class _Branches:
             self.main.wait_stream(s)
 
 
+# conv pool + LayerNorm of the q/k/v branches in one launch where dcc_pool_ln_fwd applies (bf16, head_dim 96);
+# DCC_FUSED_POOL_LN=0 keeps the two-kernel path for A/B runs
+FUSED_POOL_LN = os.environ.get("DCC_FUSED_POOL_LN", "1") != "0"
+
+
 class MvitAttnCoreFn(torch.autograd.Function):
     """qkv -> Pool(q,k,v) (dw conv3d + LayerNorm) -> [3-D RoPE] -> rel-pos tables -> flash attention (+ residual pool).
 
@@ -516,8 +522,12 @@ class MvitAttnCoreFn(torch.autograd.Function):
                                                       ("k", wk, gk, bk, Kf.view(-1, DQK)[:, :D]),
                                                       ("v", wv, gv, bv, Vn.view(-1, D)))):
             with br.stream(i):
-                conv[name], _ = K.pool_fwd(qkv5[:, :, i], geo[name], w.detach().reshape(D, 27))
-                _, m_, r_ = K.layernorm_fwd(conv[name].view(-1, D), gam.detach(), bet.detach(), eps, out=dst)
+                if FUSED_POOL_LN and K.pool_ln_supported(qkv5[:, :, i], geo[name]):
+                    conv[name], m_, r_ = K.pool_ln_fwd(qkv5[:, :, i], geo[name], w.detach().reshape(D, 27), gam.detach(),
+                                                       bet.detach(), eps, dst)
+                else:
+                    conv[name], _ = K.pool_fwd(qkv5[:, :, i], geo[name], w.detach().reshape(D, 27))
+                    _, m_, r_ = K.layernorm_fwd(conv[name].view(-1, D), gam.detach(), bet.detach(), eps, out=dst)
                 stats[name] = (m_, r_)
         br.join()
         (mq, rq), (mk, rk), (mv, rv) = stats["q"], stats["k"], stats["v"]

@@ -331,6 +331,31 @@ def pool_fwd(x: torch.Tensor, g: PoolGeom, weight: torch.Tensor | None, out: tor
     return out, argmax
 
 
+def pool_ln_supported(x: torch.Tensor, g: PoolGeom) -> bool:
+    """Domain of the fused conv-pool + LayerNorm kernel (dcc_pool_ln_fwd)."""
+    return (x.dtype == torch.bfloat16 and g.C == 96 and g.kernel == (3, 3, 3) and g.padding == (1, 1, 1)
+            and g.stride[0] == 1 and g.stride[1] == g.stride[2] and g.stride[1] in (1, 2, 4, 8))
+
+
+def pool_ln_fwd(x: torch.Tensor, g: PoolGeom, weight: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                out: torch.Tensor):
+    """Depthwise-conv pool of x ([B, N_in, H, 96] view) + LayerNorm over the head dimension in one launch.
+    out: [B*N_out*H, 96] rows (row stride free, e.g. the first 96 columns of the [.., DQK] attention operand).
+    Returns (conv [B, N_out, H, 96], mean, rstd)."""
+    L.require_cuda(x, weight, gamma, beta, out)
+    assert x.shape == (g.B, g.n_in, g.H, g.C) and pool_ln_supported(x, g)
+    rows = g.B * g.n_out * g.H
+    assert out.shape == (rows, g.C) and out.stride(1) == 1 and out.dtype == x.dtype
+    assert weight.dtype == torch.float32 and weight.is_contiguous() and weight.numel() == g.C * 27
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    conv = torch.empty((g.B, g.n_out, g.H, g.C), device=x.device, dtype=x.dtype)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    L.call("dcc_pool_ln_fwd", L.ptr(x), L.ptr(conv), L.ptr(out), out.stride(0), L.ptr(weight), L.ptr(gamma), L.ptr(beta),
+           L.ptr(mean), L.ptr(rstd), g.dims(), _pool_strides(x, conv), float(eps), L.dt(x), L.stream())
+    return conv, mean, rstd
+
+
 def pool_bwd_data(dy: torch.Tensor, dx: torch.Tensor, g: PoolGeom, weight: torch.Tensor | None,
                   argmax: torch.Tensor | None = None):
     """dx (a [B,N_in,H,C] view, e.g. a slice of the dqkv buffer) is overwritten."""

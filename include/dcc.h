@@ -138,6 +138,13 @@ int dcc_im2col3d_u8(const uint8_t* x, const float* mean, const float* stdv, void
                     void* stream);
 int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* argmax, const int* dims, const int64_t* strides,
                  int mode, int dtype, void* stream);
+/* mvit.Pool of a q / k / v branch in ONE launch: depthwise Conv3d k=3 + the LayerNorm(head_dim) that follows it
+ * (torchvision MultiscaleAttention pool_q / pool_k / pool_v = Pool(conv, norm), called from models/video_encoder.py:232-253).
+ * bf16, head_dim 96, spatial stride 1/2/4/8.  y = conv output (saved for the LayerNorm backward, y-strides of `strides`),
+ * o = LayerNorm(y) rows in (b, n, h) order with row stride ldo (elements), mean / rstd fp32 [B*No*H].
+ * DCC_ERR_UNSUPPORTED outside that domain: use dcc_pool_fwd + dcc_layernorm_fwd. */
+int dcc_pool_ln_fwd(const void* x, void* y, void* o, int64_t ldo, const float* w, const float* gamma, const float* beta,
+                    float* mean, float* rstd, const int* dims, const int64_t* strides, float eps, int dtype, void* stream);
 int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const uint8_t* argmax, const int* dims,
                       const int64_t* strides, int mode, int dtype, int grad_dtype, void* stream);
 int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, float* workspace, const int* dims,

@@ -124,6 +124,50 @@ def test_depthwise_pool_fwd_bwd(stride, thw, H, C, B, dtype, tol):
     assert _rel(dw.view_as(w0), 2 * wr.grad) < tol
 
 
+@pytest.mark.parametrize("stride,thw,H,B", [((1, 1, 1), (4, 14, 14), 4, 3), ((1, 1, 1), (2, 5, 3), 8, 2),
+                                           ((1, 2, 2), (3, 14, 14), 2, 3), ((1, 2, 2), (3, 7, 7), 4, 2),
+                                           ((1, 4, 4), (2, 28, 28), 2, 2), ((1, 8, 8), (2, 56, 56), 1, 2),
+                                           ((1, 1, 1), (8, 7, 7), 8, 5), ((1, 2, 2), (4, 56, 56), 2, 5)])
+@pytest.mark.parametrize("ldo", [96, 128])
+def test_fused_pool_layernorm_fwd(stride, thw, H, B, ldo):
+    """mvit.Pool = depthwise Conv3d + LayerNorm(head_dim) in one launch (dcc_pool_ln_fwd): against the torch fp32 reference of
+    both ops on the bf16-rounded conv output, and against the two-kernel path (conv bit-identical; the LayerNorm differs only
+    by the order of its row sums).  x is the strided q/k/v slice of a qkv buffer, out a column slice of a wider operand."""
+    from deepcoro_clip_amd import kernels as K
+
+    C = 96
+    g = _gen(11)
+    geo = K.PoolGeom(B, H, C, thw, (3, 3, 3), stride, (1, 1, 1), True)
+    qkv = (torch.randn(B, geo.n_in, 3, H, C, generator=g) * 0.7).bfloat16().cuda()
+    x = qkv[:, :, 1]
+    assert K.pool_ln_supported(x, geo)
+    w = (torch.randn(C, 27, generator=g) * 0.2).cuda()
+    gam = (torch.rand(C, generator=g) + 0.5).cuda()
+    bet = (torch.randn(C, generator=g) * 0.1).cuda()
+    rows = B * geo.n_out * H
+    wide = torch.full((rows, ldo), 7.0, device="cuda", dtype=torch.bfloat16)
+    out = wide[:, :C]
+    conv, mean, rstd = K.pool_ln_fwd(x, geo, w, gam, bet, 1e-6, out)
+    # two-kernel path
+    conv2, _ = K.pool_fwd(x, geo, w)
+    y2, mean2, rstd2 = K.layernorm_fwd(conv2.view(rows, C), gam, bet, 1e-6)
+    assert torch.equal(conv, conv2)
+    assert (out.float() - y2.float()).abs().max().item() <= 2.0 ** -5  # one bf16 ulp at |y| < 4
+    assert _rel(mean, mean2) < 1e-5 and _rel(rstd, rstd2) < 1e-5
+    if ldo > C:
+        assert torch.all(wide[:, C:] == 7.0)  # the columns beyond the head dimension are not touched
+    # torch reference
+    xf = x.float().cpu()
+    cls, tok = xf[:, :1], xf[:, 1:]
+    t = tok.permute(0, 2, 3, 1).reshape(B * H, C, *thw)
+    o = F.conv3d(t, w.cpu().view(C, 1, 3, 3, 3), None, stride, (1, 1, 1), groups=C)
+    o = torch.cat([cls, o.reshape(B, H, C, -1).permute(0, 3, 1, 2)], 1)
+    assert _rel(conv.float().cpu(), o) < 1e-2
+    ref = F.layer_norm(conv.float().cpu(), (C,), gam.cpu(), bet.cpu(), 1e-6).reshape(rows, C)
+    assert _rel(out.float().cpu(), ref) < 1e-2
+    assert _rel(mean.cpu(), conv.float().cpu().mean(-1).reshape(-1)) < 1e-4
+
+
 @pytest.mark.parametrize("C", [192, 768])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool_skip_fwd_bwd(dtype, C):
