@@ -489,6 +489,9 @@ class _Branches:
 # conv pool + LayerNorm of the q/k/v branches in one launch where dcc_pool_ln_fwd applies (bf16, head_dim 96);
 # DCC_FUSED_POOL_LN=0 keeps the two-kernel path for A/B runs
 FUSED_POOL_LN = os.environ.get("DCC_FUSED_POOL_LN", "1") != "0"
+# forward rel-pos inner products without the [rows, L] P tensor where that is faster (dcc_relpos_aug_fwd: bf16, 7 x 7 key
+# grids); DCC_FUSED_RELPOS=0 keeps the stacked-table GEMM + gather everywhere
+FUSED_RELPOS = os.environ.get("DCC_FUSED_RELPOS", "1") != "0"
 
 
 class MvitAttnCoreFn(torch.autograd.Function):
@@ -541,11 +544,15 @@ class MvitAttnCoreFn(torch.autograd.Function):
         lens = (rel_h.shape[0], rel_w.shape[0], rel_t.shape[0])
         Lp = 8 * ((sum(lens) + 7) // 8)
         Rcat = stacked_tables((rel_h, rel_w, rel_t), Lp, D, dt)
-        q2d = Qf.view(-1, DQK)[:, :D]
-        P = K.gemm(q2d, Rcat)
         dims_q = K.relpos_dims(B, H, D, A, Lp, q_thw, k_thw, lens)
-        K.relpos_gather(Qf, P, idx, dims_q, scale)
-        del P
+        fused_rel = FUSED_RELPOS and K.relpos_fused_supported(Qf, D, A, k_thw)
+        if fused_rel:  # products only against the table rows each query uses, straight from q: no P tensor
+            K.relpos_aug_fwd(Qf, Rcat, idx, dims_q, scale)
+        else:
+            q2d = Qf.view(-1, DQK)[:, :D]
+            P = K.gemm(q2d, Rcat)
+            K.relpos_gather(Qf, P, idx, dims_q, scale)
+            del P
         K.relpos_kaug(Kf, dims_q)
         residual = rope is None
         O, lse = K.attn_fwd(Qf, Kf, Vn, scale=scale, residual=residual, res_start=1)
@@ -611,9 +618,9 @@ class MvitAttnCoreFn(torch.autograd.Function):
         K.relpos_scatter(dQf, dP, cfg["inv"], dims_q, scale)
         q2d = Qf.view(-1, DQK)[:, :D]
         drel_cat = wgrad(dP, q2d)
-        drel = (drel_cat[:lens[0]], drel_cat[lens[0]:lens[0] + lens[1]], drel_cat[lens[0] + lens[1]:sum(lens)])
         dq = K.gemm(dP, Rcat, b_km=True, resid=dQf.view(-1, DQK)[:, :D]).view(B, Nq, H, D)
         del dP
+        drel = (drel_cat[:lens[0]], drel_cat[lens[0]:lens[0] + lens[1]], drel_cat[lens[0] + lens[1]:sum(lens)])
         if rope is not None:
             K.rope(dq, dq, rope["cos_q"], rope["sin_q"], backward=True)
         pool_branch("q", 0, dq, cq, mq, rq, gq, wq)

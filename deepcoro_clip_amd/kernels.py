@@ -426,6 +426,20 @@ def relpos_scatter(dQf, dP, inv, dims, scale):
            _i64(_strides3(dQf)), float(scale), L.dt(dQf), L.stream())
 
 
+def relpos_fused_supported(Qf: torch.Tensor, D: int, A: int, k_thw) -> bool:
+    """Domain of dcc_relpos_aug_fwd (bf16, head_dim 96, 32 augmentation columns: the 7 x 7 key grids; with the 64 columns
+    of the 14 x 14 key grids the stacked-table GEMM + gather is faster, tools/relpos_bench.py)."""
+    return Qf.dtype == torch.bfloat16 and D == 96 and A == 32 and sum(k_thw) <= 32
+
+
+def relpos_aug_fwd(Qf, Rcat, idx, dims, scale):
+    """Qf[..., D:] = rel-pos inner products of Qf[..., :D] against the table rows each query uses (no P tensor)."""
+    L.require_cuda(Qf, Rcat)
+    assert Rcat.is_contiguous() and Rcat.dtype == Qf.dtype
+    L.call("dcc_relpos_aug_fwd", L.ptr(Qf), L.ptr(Rcat), L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims,
+           _i64(_strides3(Qf)), float(scale), L.dt(Qf), L.stream())
+
+
 def relpos_kaug(Kf, dims):
     L.require_cuda(Kf)
     L.call("dcc_relpos_kaug", L.ptr(Kf), dims, _i64(_strides3(Kf)), L.dt(Kf), L.stream())

@@ -108,6 +108,12 @@ int dcc_relpos_gather(void* Qf, const void* P, const int* idx_h, const int* idx_
 int dcc_relpos_scatter(const void* dQf, void* dP, const int* inv_h, const int* inv_w, const int* inv_t,
                        const int* dims, const int64_t* strides, float scale, int dtype, void* stream);
 int dcc_relpos_kaug(void* Kf, const int* dims, const int64_t* strides, int dtype, void* stream);
+/* Fused forward (bf16, D == 96, A == 32): the products are taken only against the k_h + k_w + k_t table rows a query uses,
+ * straight from the q columns of Qf, so P is never materialised.  Rcat = the three tables stacked [L][D] (h | w | t).
+ * Qf[row][D + j] = <q_row, Rcat[base_a + idx_a[coord_a][j_a]]> / scale (zeros in the padding columns and class-token rows)
+ * = dcc_gemm(q, Rcat) + dcc_relpos_gather.  DCC_ERR_UNSUPPORTED outside that domain. */
+int dcc_relpos_aug_fwd(void* Qf, const void* Rcat, const int* idx_h, const int* idx_w, const int* idx_t, const int* dims,
+                       const int64_t* strides, float scale, int dtype, void* stream);
 
 /* ---- LayerNorm (csrc/norm.hip): nn.LayerNorm in MViT blocks / Pool.norm_act / BERT / aggregator /
  * attention pool (models/video_aggregator.py:15,24,99; models/attention_pool.py:53,94). */

@@ -1,0 +1,64 @@
+"""Rel-pos path of one MViT block at the headline shapes: fused kernels against the stacked-table GEMM + gather / scatter path.
+usage: python tools/relpos_bench.py [blk ...]"""
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from deepcoro_clip_amd import functional as Fn, kernels as K
+
+CLIPS = 32
+BLOCKS = {  # heads, q grid, k grid
+    "blk0": (1, (8, 56, 56), (8, 7, 7)), "blk1": (2, (8, 28, 28), (8, 14, 14)), "blk2": (2, (8, 28, 28), (8, 7, 7)),
+    "blk3": (4, (8, 14, 14), (8, 14, 14)), "blk4-13": (4, (8, 14, 14), (8, 7, 7)), "blk14": (8, (8, 7, 7), (8, 14, 14)),
+    "blk15": (8, (8, 7, 7), (8, 7, 7)),
+}
+
+
+def t(fn, reps=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3
+
+
+def main():
+    D = 96
+    for name in (sys.argv[1:] or list(BLOCKS)):
+        H, q_thw, k_thw = BLOCKS[name]
+        B = CLIPS
+        A = Fn.relpos_aug_width(k_thw); DQK = D + A
+        Nq = q_thw[0] * q_thw[1] * q_thw[2] + 1
+        idx, inv, lens = [], [], []
+        for a in (1, 2, 0):
+            qs, ks = q_thw[a], k_thw[a]
+            d = 2 * max(qs, ks) - 1
+            ix = Fn.relpos_index(qs, ks)
+            iv = torch.full((qs, d), -1, dtype=torch.int32)
+            iv.scatter_(1, ix.long(), torch.arange(ks, dtype=torch.int32).expand(qs, ks).contiguous())
+            idx.append(ix.cuda()); inv.append(iv.contiguous().cuda()); lens.append(d)
+        Lp = 8 * ((sum(lens) + 7) // 8)
+        Rcat = (torch.randn(Lp, D, device="cuda") * 0.5).bfloat16()
+        dims = K.relpos_dims(B, H, D, A, Lp, q_thw, k_thw, lens)
+        Qf = (torch.randn(B, Nq, H, DQK, device="cuda") * 0.5).bfloat16()
+        dQf = torch.randn_like(Qf)
+        scale = D ** -0.5
+        rows = B * Nq * H
+
+        def old_f():
+            P = K.gemm(Qf.view(-1, DQK)[:, :D], Rcat)
+            K.relpos_gather(Qf, P, idx, dims, scale)
+
+        def old_b():
+            dP = torch.empty(rows, Lp, device="cuda", dtype=torch.bfloat16)
+            K.relpos_scatter(dQf, dP, inv, dims, scale)
+            Fn.wgrad(dP, Qf.view(-1, DQK)[:, :D])
+            K.gemm(dP, Rcat, b_km=True, resid=dQf.view(-1, DQK)[:, :D])
+
+        fused = f"{t(lambda: K.relpos_aug_fwd(Qf, Rcat, idx, dims, scale)):7.1f} us" if K.relpos_fused_supported(Qf, D, A, k_thw) else "   n/a"
+        print(f"{name}: rows {rows}, L {Lp}, A {A}:  fwd gemm+gather {t(old_f):7.1f} us, fused {fused};"
+              f"  bwd scatter+2 gemm {t(old_b):7.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
