@@ -605,8 +605,8 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   // persistent LDS-DMA ring kernel: the towers' large GEMMs, and (measured, scratch/gemm_small.py) also the small grids
   // of the text tower and the deep-K rel-pos table gradients, where its 3-4 stage pipeline hides the per-step load
   // latency the tiled kernel exposes (variant 6 restores the tiled kernel for small grids)
-  if (in_dtype == DCC_BF16 && aligned && (variant == 8 || variant == 9)) {  // A/B knob: force the wide-tile kernel
-    const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, variant == 8 ? 256 : 128, st);
+  if (in_dtype == DCC_BF16 && aligned && (variant == 8 || variant == 9 || variant == 11)) {  // A/B knob: force the wide-tile kernel
+    const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, variant == 8 ? 256 : 128, variant == 11 ? 3 : 4, st);
     if (rc != DCC_ERR_UNSUPPORTED) return rc;
   }
   // Measured on MI355X (tools/gemm_bench.py, profiles/r02_gemm_bench.txt): forward GEMMs with a short reduction and a
@@ -616,13 +616,19 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   static const int wide_mode = getenv("DCC_WIDE_MODE") ? atoi(getenv("DCC_WIDE_MODE")) : 0;  // experiments: 1-3 widen the choice
   if (in_dtype == DCC_BF16 && out_dtype == DCC_BF16 && aligned && variant == 0 && !a_km && batch == 1 && splitk == 1 &&
       !(flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && M >= 8192 && K >= 128) {
-    int bn = 0;
-    if (!b_km && N >= 1024 && K <= 768) bn = 256;
-    if (wide_mode >= 1 && b_km && N >= 1024 && K <= 768) bn = 256;            // dgelu / NT with a wide output
-    if (wide_mode >= 2 && N >= 256 && N < 1024) bn = (N % 256 == 0) ? 256 : 128;  // N = C outputs
-    if (wide_mode >= 3 && bn == 0 && N >= 1024) bn = 256;                      // deep K too
+    int bn = 0, ns = 4;
+    if (!b_km && N >= 1024 && K <= 768) {
+      // one output tensor (qkv): 256 x 128 tiles, two workgroups per CU, 66 us against 74 (256 x 256) and 78 (ring) at
+      // M 50208 N 1152 K 384; fc1 (pre-activation + GELU: two stores) stays on 256 x 256 (141 against 148)
+      if (flags & GEMM_SAVE_PRE) bn = 256; else { bn = 128; ns = 3; }
+    }
+    if (b_km && (flags & GEMM_DGELU) && N >= 1024 && K <= 768 && wide_mode != 4) { bn = 128; ns = 3; }  // 147 us against 156 (ring)
+    if (wide_mode == 4 && !b_km && N >= 1024 && K <= 768) { bn = 256; ns = 4; }   // A/B: the round-2 choice
+    if (wide_mode >= 1 && wide_mode <= 3 && b_km && N >= 1024 && K <= 768) { bn = 256; ns = 4; }  // dgelu / NT with a wide output
+    if (wide_mode >= 2 && wide_mode <= 3 && N >= 256 && N < 1024) { bn = (N % 256 == 0) ? 256 : 128; ns = 4; }  // N = C outputs
+    if (wide_mode == 3 && bn == 0 && N >= 1024) { bn = 256; ns = 4; }              // deep K too
     if (bn) {
-      const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, bn, st);
+      const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, bn, ns, st);
       if (rc != DCC_ERR_UNSUPPORTED) return rc;
     }
   }

@@ -22,7 +22,6 @@ namespace {
 
 constexpr int WNT = 512;
 constexpr int WBM = 256, WBK = 32;     // K elements per ring stage
-constexpr int WNS = 4, WD = WNS - 1;   // stages / steps in flight
 constexpr int SUB_B = 128 * WBK * 2;   // one 128-wide sub-tile of a stage (8 KB)
 
 __device__ __forceinline__ int wswz_km128(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
@@ -52,8 +51,12 @@ __device__ __forceinline__ bf16x8 wfrag_km(const char* sub, int t0, int s, int l
 
 struct WGeo { int tiles, tilesN, ksteps, per, items; };
 
-template <typename TC, bool A_KM, bool B_KM, int BN>
-__global__ __launch_bounds__(WNT, 2) void gemm_wide_kernel(GemmParams p, WGeo geo) {
+// NS = ring depth (stages; NS - 1 steps in flight).  BN = 256: NS = 4, 128 KB of LDS, one workgroup per CU, two waves per SIMD.
+// BN = 128, NS = 3: 72 KB and <= 128 VGPRs, so TWO workgroups share a CU and one's epilogue (LDS transposition + stores,
+// as long as its 12-step main loop when K = 384) runs under the other's MFMAs.
+template <typename TC, bool A_KM, bool B_KM, int BN, int NS>
+__global__ __launch_bounds__(WNT, (BN == 128 && NS == 3) ? 4 : 2) void gemm_wide_kernel(GemmParams p, WGeo geo) {
+  constexpr int WNS = NS, WD = NS - 1;   // stages / steps in flight
   constexpr bool OUT16 = sizeof(TC) == 2;
   constexpr int NSA = WBM / 128, NSB = BN / 128;           // sub-tiles per stage
   constexpr int STAGE = (NSA + NSB) * SUB_B;
@@ -279,14 +282,15 @@ __global__ __launch_bounds__(WNT, 2) void gemm_wide_kernel(GemmParams p, WGeo ge
   }
 }
 
-template <typename TC, bool A_KM, bool B_KM, int BN>
+template <typename TC, bool A_KM, bool B_KM, int BN, int NS>
 int wide_launch(const GemmParams& p, const WGeo& geo, hipStream_t st) {
+  constexpr int WNS = NS;
   constexpr int NSA = WBM / 128, NSB = BN / 128;
   constexpr int STAGE = (NSA + NSB) * SUB_B;
   constexpr int WM = BN == 256 ? 2 : 4;
   constexpr int STRIP = 8 * (WBM / WM) * (2 * 64 + 16);
   constexpr int LDS = (WNS * STAGE > STRIP) ? WNS * STAGE : STRIP;
-  auto kern = gemm_wide_kernel<TC, A_KM, B_KM, BN>;
+  auto kern = gemm_wide_kernel<TC, A_KM, B_KM, BN, NS>;
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -301,7 +305,7 @@ int wide_launch(const GemmParams& p, const WGeo& geo, hipStream_t st) {
 }  // namespace
 
 // Returns DCC_ERR_UNSUPPORTED for shapes / layouts outside the kernel's domain (the caller falls back to the ring kernel).
-int dcc_gemm_wide_launch(const GemmParams& p, int a_km, int b_km, int out_dtype, int bn, hipStream_t st) {
+int dcc_gemm_wide_launch(const GemmParams& p, int a_km, int b_km, int out_dtype, int bn, int ns, hipStream_t st) {
   if ((p.lda % 8) || (p.ldb % 8) || (p.sA % 8) || (p.sB % 8) || (p.ldc % 8) || (p.N % 8) || (p.sC % 8)) return DCC_ERR_UNSUPPORTED;
   if ((a_km && (p.M % 8)) || (b_km && (p.N % 8))) return DCC_ERR_UNSUPPORTED;
   if ((!a_km || !b_km) && (p.K % 8)) return DCC_ERR_UNSUPPORTED;
@@ -314,7 +318,7 @@ int dcc_gemm_wide_launch(const GemmParams& p, int a_km, int b_km, int out_dtype,
   if (extA >= (1LL << 31) || extB >= (1LL << 31)) return DCC_ERR_UNSUPPORTED;
   if (out_dtype == DCC_BF16 && (p.splitk > 1 || (p.flags & (GEMM_ACCUM | GEMM_COLSUM_A)))) return DCC_ERR_UNSUPPORTED;
   if (out_dtype == DCC_F32 && (p.flags & (GEMM_GELU | GEMM_DGELU | GEMM_SAVE_PRE | GEMM_RESID))) return DCC_ERR_UNSUPPORTED;
-  if (bn != 128 && bn != 256) return DCC_ERR_ARG;
+  if ((bn != 128 && bn != 256) || (ns != 3 && ns != 4) || (ns == 3 && bn != 128)) return DCC_ERR_ARG;
   WGeo geo;
   const int tilesM = (p.M + WBM - 1) / WBM;
   geo.tilesN = (p.N + bn - 1) / bn;
@@ -324,15 +328,15 @@ int dcc_gemm_wide_launch(const GemmParams& p, int a_km, int b_km, int out_dtype,
   geo.items = (int)items;
   geo.ksteps = (p.K + WBK - 1) / WBK;
   geo.per = (geo.ksteps + p.splitk - 1) / p.splitk;
-#define WIDE(TC_, BN_)                                                                 \
+#define WIDE(TC_, BN_, NS_)                                                            \
   do {                                                                                 \
-    if (!a_km && !b_km) return wide_launch<TC_, false, false, BN_>(p, geo, st);        \
-    if (!a_km && b_km) return wide_launch<TC_, false, true, BN_>(p, geo, st);          \
-    if (a_km && !b_km) return wide_launch<TC_, true, false, BN_>(p, geo, st);          \
-    return wide_launch<TC_, true, true, BN_>(p, geo, st);                              \
+    if (!a_km && !b_km) return wide_launch<TC_, false, false, BN_, NS_>(p, geo, st);   \
+    if (!a_km && b_km) return wide_launch<TC_, false, true, BN_, NS_>(p, geo, st);     \
+    if (a_km && !b_km) return wide_launch<TC_, true, false, BN_, NS_>(p, geo, st);     \
+    return wide_launch<TC_, true, true, BN_, NS_>(p, geo, st);                         \
   } while (0)
-  if (out_dtype == DCC_BF16) { if (bn == 256) WIDE(bf16_t, 256); WIDE(bf16_t, 128); }
-  if (out_dtype == DCC_F32) { if (bn == 256) WIDE(float, 256); WIDE(float, 128); }
+  if (out_dtype == DCC_BF16) { if (bn == 256) WIDE(bf16_t, 256, 4); if (ns == 3) WIDE(bf16_t, 128, 3); WIDE(bf16_t, 128, 4); }
+  if (out_dtype == DCC_F32) { if (bn == 256) WIDE(float, 256, 4); if (ns == 3) WIDE(float, 128, 3); WIDE(float, 128, 4); }
 #undef WIDE
   return DCC_ERR_UNSUPPORTED;
 }
