@@ -423,16 +423,16 @@ extern "C" int dcc_relpos_aug_fwd(void* Qf, const void* Rcat, const int* idx_h, 
   if ((g.sb % 8) || (g.sn % 8) || (g.sh % 8) || (((uintptr_t)Qf) & 15) || (((uintptr_t)Rcat) & 15)) return DCC_ERR_UNSUPPORTED;
   const int64_t rows = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H;
   const size_t lds = (size_t)g.L * 256 + (size_t)(g.qh * g.kh + g.qw * g.kw + g.qt * g.kt) * 4;
-  if (rows >= (1LL << 31) || lds > 64 * 1024) return DCC_ERR_UNSUPPORTED;
+  if (rows >= (1LL << 31) || lds > 96 * 1024) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const RelDiv dv{mkdiv(g.H), mkdiv(g.qt * g.qh * g.qw + g.has_cls), mkdiv(g.qw * g.qh), mkdiv(g.qw), mkdiv(1), mkdiv(1)};
   int64_t nb = (rows + 15) / 16;
-  const int cap = 256 * (lds > 48 * 1024 ? 2 : 3) * 2;   // persistent: the table staging is amortised over many rows
+  const int cap = 256 * (lds > 76 * 1024 ? 1 : (lds > 48 * 1024 ? 2 : 3)) * 2;   // persistent: the table staging is amortised over many rows
   if (nb > cap) nb = cap;
   auto k2 = relpos_aug_fwd_kernel<2>;
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
       return DCC_ERR_LAUNCH;
     configured = true;
   }

@@ -545,7 +545,7 @@ class MvitAttnCoreFn(torch.autograd.Function):
         Lp = 8 * ((sum(lens) + 7) // 8)
         Rcat = stacked_tables((rel_h, rel_w, rel_t), Lp, D, dt)
         dims_q = K.relpos_dims(B, H, D, A, Lp, q_thw, k_thw, lens)
-        fused_rel = FUSED_RELPOS and K.relpos_fused_supported(Qf, D, A, k_thw)
+        fused_rel = FUSED_RELPOS and K.relpos_fused_supported(Qf, D, A, k_thw, q_thw, Lp)
         if fused_rel:  # products only against the table rows each query uses, straight from q: no P tensor
             K.relpos_aug_fwd(Qf, Rcat, idx, dims_q, scale)
         else:

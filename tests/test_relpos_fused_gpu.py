@@ -24,7 +24,7 @@ def _tables(q_thw, k_thw, D, g):
 
 @pytest.mark.parametrize("B,H,q_thw,k_thw", [(2, 4, (8, 14, 14), (8, 7, 7)), (1, 2, (8, 28, 28), (8, 7, 7)),
                                              (1, 1, (8, 56, 56), (8, 7, 7)), (2, 8, (8, 7, 7), (8, 7, 7)),
-                                             (3, 2, (4, 14, 14), (4, 7, 7))])
+                                             (3, 2, (4, 14, 14), (4, 7, 7)), (1, 1, (16, 56, 56), (16, 7, 7))])
 def test_fused_relpos_matches_gemm_path_and_reference(B, H, q_thw, k_thw):
     from deepcoro_clip_amd import functional as Fn
     from deepcoro_clip_amd import kernels as K
@@ -32,7 +32,6 @@ def test_fused_relpos_matches_gemm_path_and_reference(B, H, q_thw, k_thw):
     D = 96
     g = torch.Generator().manual_seed(5)
     A = Fn.relpos_aug_width(k_thw)
-    assert K.relpos_fused_supported(torch.empty(1, dtype=torch.bfloat16), D, A, k_thw)
     DQK = D + A
     Nq = q_thw[0] * q_thw[1] * q_thw[2] + 1
     idx, inv, tabs = _tables(q_thw, k_thw, D, g)
@@ -43,6 +42,7 @@ def test_fused_relpos_matches_gemm_path_and_reference(B, H, q_thw, k_thw):
     Rcat = Rcat.cuda()
     scale = 1.0 / D ** 0.5
     dims = K.relpos_dims(B, H, D, A, Lp, q_thw, k_thw, lens)
+    assert K.relpos_fused_supported(torch.empty(1, dtype=torch.bfloat16), D, A, k_thw, q_thw, Lp)
     q = (torch.randn(B, Nq, H, D, generator=g) * 0.5).bfloat16()
     Qa = torch.full((B, Nq, H, DQK), 3.0, dtype=torch.bfloat16).cuda()
     Qa[..., :D] = q.cuda()
