@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
                   bf16x8 o;
 #pragma unroll
                   for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-                  *reinterpret_cast<bf16x8*>(ap) = o;
+                  STREAM_STORE(reinterpret_cast<bf16x8*>(ap), o);
                 } else {
                   *reinterpret_cast<f32x4*>(ap) = f32x4{v[0], v[1], v[2], v[3]};
                   *reinterpret_cast<f32x4*>(ap + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
                 for (int e = 0; e < 8; ++e) v[e] = gelu_for<TC>(v[e]);
               }
               if (p.flags & GEMM_DGELU) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col);
+                const bf16x8 a = STREAM_LOAD(reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf16((float)a[e]);
               }
@@ -666,7 +666,10 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
           const int row = cur.m0 + 16 * k + 4 * w4 + (lane >> 4);
 #pragma unroll
           for (int e = 0; e < 8; ++e) pre[k][e] = (bf16_t)0.0f;
-          if (row < p.M && col < p.N) pre[k] = *reinterpret_cast<const bf16x8*>(X + (int64_t)row * ldxx + col);
+          if (row < p.M && col < p.N) {
+            const bf16x8* xp = reinterpret_cast<const bf16x8*>(X + (int64_t)row * ldxx + col);
+            pre[k] = (p.flags & GEMM_RESID) ? *xp : STREAM_LOAD(xp);   // the saved pre-activation is read exactly once
+          }
         }
       }
       const bool last = (t + 1 == nitems);
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (float)mv[e];
-        if (p.flags & GEMM_SAVE_PRE) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col) = mv;
+        if (p.flags & GEMM_SAVE_PRE) STREAM_STORE(reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col), mv);
         if (p.flags & GEMM_GELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = gelu_bf16(v[e]);
