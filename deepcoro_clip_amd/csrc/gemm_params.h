@@ -39,4 +39,3 @@ int dcc_gemm_ring_launch(const GemmParams& p, int a_km, int b_km, int out_dtype,
 int dcc_gemm_ring_launch_fp8(const GemmParams& p, hipStream_t stream);
 // Wide-tile kernel (gemm_wide.hip): 256 x bn tiles (bn = 256 | 128), 8 waves.  DCC_ERR_UNSUPPORTED outside its domain.
 int dcc_gemm_wide_launch(const GemmParams& p, int a_km, int b_km, int out_dtype, int bn, int ns, hipStream_t stream);
-int dcc_gemm_wide2_launch(const GemmParams& p, int a_km, int b_km, int out_dtype, hipStream_t stream);

@@ -302,214 +302,6 @@ int wide_launch(const GemmParams& p, const WGeo& geo, hipStream_t st) {
   return dcc_check_launch();
 }
 
-// ================================================================================================ crew variant
-// 256 x 128 tile, PERSISTENT, 8 compute waves (load + MFMA, exactly the loop above) + 8 storer waves.  Ablation of the kernel
-// above at fc1-forward: 69 us of main loops + 45 us of stores + 23 us of activation, strictly one after the
-// other, because the waves that issue the stores are the waves that would run the next MFMAs, and gfx9 counts stores on the
-// same vmcnt as the ring's loads.  Here the compute waves hand the finished tile (alpha * acc + bias, rounded to bf16 once)
-// to an LDS mailbox and go on to the next tile; the storer waves read the mailbox, run the activation / residual / saved
-// pre-activation epilogue and store, spread over the K-steps of the next tile (all 16 waves meet at the ring's one barrier
-// per K-step, so the crews share one cadence: the storers take iterations q*8/nk .. (q+1)*8/nk of their 8 per tile in step q).
-// bf16 output, splitk == 1, batch == 1.
-constexpr int W2_NC = 8, W2_NSW = 8, W2_NT = 64 * (W2_NC + W2_NSW);
-constexpr int W2_BN = 128, W2_NS = 3, W2_WD = W2_NS - 1;
-constexpr int W2_STAGE = 3 * SUB_B;               // two A sub-tiles + one B sub-tile
-constexpr int W2_MBP = W2_BN * 2 + 16;            // mailbox row pitch in bytes
-constexpr int W2_LDS = W2_NS * W2_STAGE + WBM * W2_MBP;
-
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(W2_NT) void gemm_wide2_kernel(GemmParams p, WGeo geo) {
-  constexpr int NSA = 2, PPW = 3, WN = 2, RW = 64, CW = 64, TI = 2, TJ = 2;
-  constexpr int WNS = W2_NS, WD = W2_WD, STAGE = W2_STAGE;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* mbox = smem + WNS * STAGE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
-  const int G = gridDim.x, bid = blockIdx.x;
-  const int item0 = (bid & 7) * (G >> 3) + (bid >> 3);   // XCD-aware: the workgroups of one XCD walk neighbouring tiles
-  const int nk = geo.ksteps;
-
-  if (wave >= W2_NC) {
-    // ============================================================================================ storer waves
-    const int sw = wave - W2_NC;
-    bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
-    const bf16_t* X = reinterpret_cast<const bf16_t*>((p.flags & GEMM_RESID) ? p.R : p.aux);
-    const int64_t ldxx = (p.flags & GEMM_RESID) ? p.ldr : p.ldaux;
-    auto drain = [&](int item, int j0, int j1) {   // iterations j0 .. j1-1 (of 8) of the tile in the mailbox
-      const int tm = item / geo.tilesN, tn = item - tm * geo.tilesN;
-      const int m0 = tm * WBM, n0 = tn * W2_BN;
-      for (int j = j0; j < j1; ++j) {
-        const int c = (j * W2_NSW + sw) * 64 + lane, r = c >> 4, c8 = (c & 15) * 8;
-        const bf16x8 mv = *reinterpret_cast<const bf16x8*>(mbox + r * W2_MBP + c8 * 2);
-        const int row = m0 + r, col = n0 + c8;
-        if (row >= p.M || col >= p.N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)mv[e];
-        if (p.flags & GEMM_SAVE_PRE)
-          STREAM_STORE(reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col), mv);
-        if (p.flags & GEMM_GELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_bf16(v[e]);
-        }
-        if (p.flags & GEMM_DGELU) {
-          const bf16x8 a = STREAM_LOAD(reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col));
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf16((float)a[e]);
-        }
-        if (p.flags & GEMM_RESID) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(X + (int64_t)row * ldxx + col);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)a[e];
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-        *reinterpret_cast<bf16x8*>(C + (int64_t)row * p.ldc + col) = o;
-      }
-    };
-    int prev = -1;
-    for (int item = item0; item < geo.items; item += G) {
-      for (int q = 0; q < nk; ++q) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (prev >= 0) drain(prev, q * 8 / nk, (q + 1) * 8 / nk);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every mailbox read of this crew has returned
-      __builtin_amdgcn_s_barrier();   // the mailbox is free (this crew is done with the previous tile)
-      __builtin_amdgcn_s_barrier();   // the mailbox holds this item's tile
-      asm volatile("" ::: "memory");
-      prev = item;
-    }
-    if (prev >= 0) drain(prev, 0, 8);
-    return;
-  }
-
-  // ============================================================================================== compute waves
-  const int wr = wave / WN, wc = wave % WN;
-  auto bytes_left = [](bool km, int64_t ld, int rem, int K) -> unsigned {
-    const int64_t elems = rem <= 0 ? 0 : (km ? (int64_t)(K - 1) * ld + rem : (int64_t)(rem - 1) * ld + K);
-    return (unsigned)(elems * 2);
-  };
-  constexpr int OOB = 0x7fffff00;
-  const int kstrideA = A_KM ? WBK * (int)p.lda * 2 : WBK * 2, kstrideB = B_KM ? WBK * (int)p.ldb * 2 : WBK * 2;
-  int voff[PPW], kc[PPW];
-#pragma unroll
-  for (int j = 0; j < PPW; ++j) {   // item-independent part of the DMA addresses (offsets from the tile origin)
-    const int g = wave * PPW + j;
-    const bool isA = g < NSA * 8;
-    const int gg = isA ? g : g - NSA * 8, sub = gg >> 3, pin = gg & 7;
-    const bool km = isA ? A_KM : B_KM;
-    const int ld = (int)(isA ? p.lda : p.ldb);
-    kc[j] = 0;
-    if (km) { const int R = pin * 4 + (lane >> 4), c = (lane & 15) ^ wswz_km128(R); voff[j] = (R * ld + sub * 128 + c * 8) * 2; }
-    else { const int R = pin * 16 + (lane >> 2), c = (lane & 3) ^ ((R >> 2) & 3); voff[j] = ((sub * 128 + R) * ld + c * 8) * 2; kc[j] = c * 8; }
-  }
-  for (int item = item0; item < geo.items; item += G) {
-    const int tm = item / geo.tilesN, tn = item - tm * geo.tilesN;
-    const int m0 = tm * WBM, n0 = tn * W2_BN;
-    const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + (A_KM ? (int64_t)m0 : (int64_t)m0 * p.lda);
-    const bf16_t* Bb = reinterpret_cast<const bf16_t*>(p.B) + (B_KM ? (int64_t)n0 : (int64_t)n0 * p.ldb);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ab), 0, bytes_left(A_KM, p.lda, p.M - m0, p.K), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bb), 0, bytes_left(B_KM, p.ldb, p.N - n0, p.K), 0x00020000);
-    auto issue_piece = [&](int j, int stage, int kb, bool live) {
-      const int g = wave * PPW + j;
-      const bool isA = g < NSA * 8;
-      const bool km = isA ? A_KM : B_KM;
-      const int vo = (!live || (!km && kb * WBK + kc[j] >= p.K)) ? OOB : voff[j] + kb * (isA ? kstrideA : kstrideB);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, LDS_PTR(void, smem + stage * STAGE + g * 1024), 16, vo, 0, 0, 0);
-    };
-    f32x16 acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-#pragma unroll
-    for (int d = 0; d < WD; ++d) {
-#pragma unroll
-      for (int j = 0; j < PPW; ++j) issue_piece(j, d, d, d < nk);
-    }
-    for (int q = 0; q < nk; ++q) {
-      wwait_vm<(WD - 1) * PPW>();
-      __builtin_amdgcn_s_barrier();
-      const char* sa = smem + (q % WNS) * STAGE;
-      const char* sb = sa + NSA * SUB_B;
-      const int nq = q + WD;
-      const bool more = nq < nk;
-      bf16x8 fa[2][TI], fb[2][TJ];
-      auto fetch = [&](int buf, int s) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-          const int r0 = wr * RW + 32 * i;
-          fa[buf][i] = A_KM ? wfrag_km(sa + (r0 >> 7) * SUB_B, r0 & 127, s, lane) : wfrag_kc(sa + (r0 >> 7) * SUB_B, r0 & 127, s, lane);
-        }
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-          const int c0 = wc * CW + 32 * j;
-          fb[buf][j] = B_KM ? wfrag_km(sb, c0, s, lane) : wfrag_kc(sb, c0, s, lane);
-        }
-      };
-      fetch(0, 0);
-#pragma unroll
-      for (int s = 0; s < WBK / 16; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < WBK / 16) fetch(cur ^ 1, s + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[i][j] = mma16(fb[cur][j], fa[cur][i], acc[i][j]);   // C^T: lanes = rows m
-          const int pos = s * TI + i;
-          if (pos < PPW) issue_piece(pos, nq % WNS, nq, more);
-        }
-      }
-    }
-    wwait_vm<0>();
-    // bias for this lane's columns n = 32 j + 8 g4 + 4 h + e
-    f32x4 bias4[TJ][4];
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int n = n0 + wc * CW + 32 * j + 8 * g4 + 4 * h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bias4[j][g4][e] = ((p.flags & GEMM_BIAS) && n + e < p.N) ? p.bias[n + e] : 0.0f;
-      }
-    __builtin_amdgcn_s_barrier();   // the storers are done with the previous tile: the mailbox is free (and so are the stages)
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        char* rowp = mbox + (wr * RW + 32 * i + (lane & 31)) * W2_MBP + (wc * CW + 32 * j + 4 * h) * 2;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[i][j][4 * g4 + e] * p.alpha + bias4[j][g4][e]);
-          *reinterpret_cast<bf16x4*>(rowp + 16 * g4) = o;
-        }
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // the mailbox holds this tile
-  }
-}
-
-template <bool A_KM, bool B_KM>
-int wide2_launch(const GemmParams& p, const WGeo& geo, hipStream_t st) {
-  auto kern = gemm_wide2_kernel<A_KM, B_KM>;
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS) != hipSuccess)
-      return DCC_ERR_LAUNCH;
-    configured = true;
-  }
-  int G = geo.items < 256 ? ((geo.items + 7) & ~7) : 256;
-  hipLaunchKernelGGL(kern, dim3(G), dim3(W2_NT), W2_LDS, st, p, geo);
-  return dcc_check_launch();
-}
-
 }  // namespace
 
 // Returns DCC_ERR_UNSUPPORTED for shapes / layouts outside the kernel's domain (the caller falls back to the ring kernel).
@@ -547,32 +339,4 @@ int dcc_gemm_wide_launch(const GemmParams& p, int a_km, int b_km, int out_dtype,
   if (out_dtype == DCC_F32) { if (bn == 256) WIDE(float, 256, 4); if (ns == 3) WIDE(float, 128, 3); WIDE(float, 128, 4); }
 #undef WIDE
   return DCC_ERR_UNSUPPORTED;
-}
-
-// Crew variant (persistent 256 x 128 tiles, separate storer waves): bf16 output, no split-K / accumulate / column sums.
-int dcc_gemm_wide2_launch(const GemmParams& p, int a_km, int b_km, int out_dtype, hipStream_t st) {
-  if (out_dtype != DCC_BF16 || p.splitk > 1 || p.batch != 1 || (p.flags & (GEMM_ACCUM | GEMM_COLSUM_A))) return DCC_ERR_UNSUPPORTED;
-  if ((p.lda % 8) || (p.ldb % 8) || (p.ldc % 8) || (p.N % 8)) return DCC_ERR_UNSUPPORTED;
-  if ((a_km && (p.M % 8)) || (b_km && (p.N % 8))) return DCC_ERR_UNSUPPORTED;
-  if ((!a_km || !b_km) && (p.K % 8)) return DCC_ERR_UNSUPPORTED;
-  if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15) || ((uintptr_t)p.C & 15)) return DCC_ERR_UNSUPPORTED;
-  if ((p.flags & GEMM_RESID) && ((p.ldr % 8) || ((uintptr_t)p.R & 15))) return DCC_ERR_UNSUPPORTED;
-  if ((p.flags & (GEMM_SAVE_PRE | GEMM_DGELU)) && ((p.ldaux % 8) || ((uintptr_t)p.aux & 15))) return DCC_ERR_UNSUPPORTED;
-  if ((p.flags & GEMM_BIAS) && ((uintptr_t)p.bias & 3)) return DCC_ERR_UNSUPPORTED;
-  const int64_t extA = (a_km ? (int64_t)p.K * p.lda : (int64_t)p.M * p.lda) * 2;
-  const int64_t extB = (b_km ? (int64_t)p.K * p.ldb : (int64_t)p.N * p.ldb) * 2;
-  if (extA >= (1LL << 31) || extB >= (1LL << 31)) return DCC_ERR_UNSUPPORTED;
-  WGeo geo;
-  const int tilesM = (p.M + WBM - 1) / WBM;
-  geo.tilesN = (p.N + W2_BN - 1) / W2_BN;
-  geo.tiles = tilesM * geo.tilesN;
-  if ((int64_t)tilesM * geo.tilesN > 0x3fffffff) return DCC_ERR_UNSUPPORTED;
-  geo.items = geo.tiles;
-  geo.ksteps = (p.K + WBK - 1) / WBK;
-  geo.per = geo.ksteps;
-  if (geo.ksteps < 1) return DCC_ERR_UNSUPPORTED;
-  if (!a_km && !b_km) return wide2_launch<false, false>(p, geo, st);
-  if (!a_km && b_km) return wide2_launch<false, true>(p, geo, st);
-  if (a_km && !b_km) return wide2_launch<true, false>(p, geo, st);
-  return wide2_launch<true, true>(p, geo, st);
 }

@@ -41,7 +41,7 @@ VAR = int(os.environ.get("DCC_GEMM_VARIANT", "0"))
 
 
 def wsplit(rows, n, k):
-    if VAR in (8, 9, 11, 12):  # 256 x (256 | 128) tiles: about one item per CU
+    if VAR in (8, 9, 11):  # 256 x (256 | 128) tiles: about one item per CU
         bn = 256 if VAR == 8 else 128
         tiles = ((n + 255) // 256) * ((k + bn - 1) // bn)
         return max(1, min(256 // tiles, rows // 256))
