@@ -206,6 +206,24 @@ __device__ __forceinline__ void store_tile_T(T* rowptr, int t, int h, const f32x
   }
 }
 
+// XCD-aware block order.  The hardware deals workgroups (x fastest) round-robin to the 8 XCDs, so the q tiles of one
+// (clip, head) — which all read that head's K / V — and the key blocks of the backward — which all stream that head's Q / dO —
+// land on 8 different L2s and every one of them fetches the shared operand (PMC: 300 MB per launch for ~110 MB of tensors).
+// Logical ids give each XCD a contiguous range of (x, head, clip) triples, x fastest: the sharers run on one XCD back to back.
+struct Blk3 { int x, y, z; };
+__device__ __forceinline__ Blk3 xcd_blk3() {
+#ifdef DCC_ATTN_NO_XCD
+  return Blk3{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+#else
+  const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+  const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const unsigned xcd = L & 7, q = total >> 3, r = total & 7;
+  const unsigned lb = xcd * q + (xcd < r ? xcd : r) + (L >> 3);
+  const unsigned t = lb / gx;
+  return Blk3{(int)(lb - t * gx), (int)(t % gy), (int)(t / gy)};
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // forward: one wave = 32 queries, block = 128 queries; keys/values staged 64 rows at a time.
 template <typename T, int DQK, int DV, bool DROP>
@@ -218,8 +236,9 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(AttnParams p) {
   float* ldsB = reinterpret_cast<float*>(smem + TK * KT::PITCH + TK * VT::PITCH);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const Blk3 blk = xcd_blk3();
+  const int b = blk.z, hd = blk.y;
+  const int q0 = blk.x * 128 + wave * 32;
   const int myq = q0 + (lane & 31);
   const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.sqb + hd * p.sqh;
   const T* K = reinterpret_cast<const T*>(p.K) + b * p.skb + hd * p.skh;
@@ -330,8 +349,9 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
   float* ldsB = reinterpret_cast<float*>(smem + TK * KT::PITCH + TK * VT::PITCH);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const Blk3 blk = xcd_blk3();
+  const int b = blk.z, hd = blk.y;
+  const int q0 = blk.x * 128 + wave * 32;
   const int myq = q0 + (lane & 31);
   const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.sqb + hd * p.sqh;
   const T* K = reinterpret_cast<const T*>(p.K) + b * p.skb + hd * p.skh;
@@ -458,8 +478,9 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
   float* ldsD = ldsL + TK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int kblk = blockIdx.x / p.qsplit, qs = blockIdx.x % p.qsplit;
+  const Blk3 blk = xcd_blk3();
+  const int b = blk.z, hd = blk.y;
+  const int kblk = blk.x / p.qsplit, qs = blk.x % p.qsplit;
   const int k0 = kblk * 128 + wave * 32;
   const int mykey = k0 + (lane & 31);
   const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.sqb + hd * p.sqh;
