@@ -129,6 +129,104 @@ __global__ __launch_bounds__(256) void im2col3d_chunk_kernel(const TI* __restric
   }
 }
 
+// Row variant (bf16 columns): a block owns one output row (clip, frame to, row ho) = Wo tokens.  The KT * KH input rows that
+// row touches are staged ONCE in LDS as bf16 (coalesced 16-byte loads, the normalisation of uint8 frames applied here, zero
+// rows / zero side margins for the padding), then every token's column row is assembled from LDS: a (kt, kh) segment of a
+// token is KW * Cin CONTIGUOUS LDS elements starting at wo * sw * Cin.  The chunk kernel above gathers every column element with
+// its own 4-byte global load — a wave-wide load there touches 20-40 cache lines and the kernel runs at the texture unit's line
+// rate (540 us for 1.03 GB at the headline shape); here global memory only sees full-row reads and 16-byte column stores.
+struct Im2colRow { int rowp, nrows, run, K, margin; };   // LDS row pitch (elements), KT*KH, KW*Cin, KT*KH*KW*Cin, pw*Cin
+
+template <typename TI>
+__global__ __launch_bounds__(256) void im2col3d_row_kernel(const TI* __restrict__ x, bf16_t* __restrict__ col, Im2colGeom g,
+                                                           Im2colRow rg, const float* __restrict__ mean,
+                                                           const float* __restrict__ stdv) {
+  constexpr bool U8 = sizeof(TI) == 1;
+  extern __shared__ __attribute__((aligned(16))) bf16_t irow[];   // [nrows][rowp]
+  const int tid = threadIdx.x;
+  const unsigned rowid = blockIdx.x;                 // (b, to, ho)
+  const unsigned q2 = fdiv(rowid, g.d_Ho);
+  const int ho = rowid - q2 * g.Ho;
+  const unsigned b = fdiv(q2, g.d_To);
+  const int to = q2 - b * g.To;
+  const int t0 = to * g.st - g.pt, h0 = ho * g.sh - g.ph;
+  const int wc = g.Wn * g.Cin;                      // elements of one input row
+  // ---- stage: zero margins, then the rows (4 elements per thread step)
+  for (int i = tid; i < rg.nrows * 2 * rg.margin; i += 256) {
+    const int r = i / (2 * rg.margin), m = i - r * 2 * rg.margin;
+    irow[r * rg.rowp + (m < rg.margin ? m : wc + m)] = (bf16_t)0.0f;
+  }
+  const int q4 = wc / 4;                            // wc % 4 == 0 (checked by the launcher)
+  for (int i = tid; i < rg.nrows * q4; i += 256) {
+    const int r = i / q4, c4 = i - r * q4;
+    const int kt = r / g.KH, kh = r - kt * g.KH;
+    const int t = t0 + kt, hh = h0 + kh;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if ((unsigned)t < (unsigned)g.Tn && (unsigned)hh < (unsigned)g.Hn) {
+      const int64_t src = (((int64_t)b * g.Tn + t) * g.Hn + hh) * wc + c4 * 4;
+      if constexpr (U8) {
+        const unsigned raw = *reinterpret_cast<const unsigned*>(x + src);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = (c4 * 4 + e) % g.Cin;
+          v[e] = ((float)((raw >> (8 * e)) & 0xffu) - mean[c]) * (1.0f / stdv[c]);   // same arithmetic as the chunk kernel
+        }
+      } else {
+        const f32x4 f = *reinterpret_cast<const f32x4*>(x + src);
+        v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+      }
+    }
+    bf16_t* d = irow + r * rg.rowp + rg.margin + c4 * 4;
+    d[0] = (bf16_t)v[0]; d[1] = (bf16_t)v[1]; d[2] = (bf16_t)v[2]; d[3] = (bf16_t)v[3];
+  }
+  __syncthreads();
+  // ---- assemble: thread = (chunk of 8 column elements, token slot); the chunk's LDS offsets are fixed per thread
+  const unsigned tl = fdiv(tid, g.d_cpt);
+  const int ch = tid - tl * g.cpt;
+  if ((int)tl >= g.tpb) return;
+  int off[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int i = ch * 8 + e;
+    const int r = i / rg.run;
+    off[e] = i < rg.K ? r * rg.rowp + (i - r * rg.run) : -1;   // -1: zero padding of the column index
+  }
+  const int step = g.sw * g.Cin;
+  bf16_t* out = col + ((int64_t)rowid * g.Wo) * g.Kp + ch * 8;
+  for (int wo = tl; wo < g.Wo; wo += g.tpb) {
+    const bf16_t* base = irow + wo * step;           // margin cancels: column w0 + kw = wo * sw - pw + kw sits at margin + that
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = off[e] >= 0 ? base[off[e]] : (bf16_t)0.0f;
+    *reinterpret_cast<bf16x8*>(out + (int64_t)wo * g.Kp) = o;
+  }
+}
+
+// launches the row kernel when its domain holds; false -> the caller uses the chunk kernel
+template <typename TI>
+bool launch_im2col_row(const TI* x, bf16_t* col, Im2colGeom g, const float* mean, const float* stdv, hipStream_t s) {
+  static const bool on = !(getenv("DCC_IM2COL_ROW") && atoi(getenv("DCC_IM2COL_ROW")) == 0);   // A/B knob
+  const int wc = g.Wn * g.Cin;
+  Im2colRow rg;
+  rg.margin = g.pw * g.Cin;
+  rg.rowp = (wc + 2 * rg.margin + 7) & ~7;
+  rg.nrows = g.KT * g.KH; rg.run = g.KW * g.Cin; rg.K = rg.nrows * rg.run;
+  const size_t lds = (size_t)rg.nrows * rg.rowp * 2;
+  // the right margin must cover the last token's window: (Wo-1)*sw - pw + KW <= Wn + pw
+  if (!on || (wc % 4) || lds > 60 * 1024 || (g.Wo - 1) * g.sw - g.pw + g.KW > g.Wn + g.pw || rg.margin < 0) return false;
+  if (sizeof(TI) == 1 ? ((uintptr_t)x & 3) || ((wc % 4) != 0) : ((uintptr_t)x & 15) != 0) return false;
+  const int64_t nrows_out = (int64_t)g.B * g.To * g.Ho;
+  if (nrows_out >= (1LL << 31)) return false;
+  auto kern = im2col3d_row_kernel<TI>;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024) != hipSuccess) return false;
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nrows_out), dim3(256), lds, s, x, col, g, rg, mean, stdv);
+  return true;
+}
+
 // ---------------------------------------------------------------- depthwise conv / max pool forward
 // one thread = one 16-byte channel chunk of one output token-head.
 template <typename T, bool MAXPOOL>
@@ -1515,6 +1613,7 @@ extern "C" int dcc_im2col3d(const float* x, void* col, int B, int T, int H, int 
       g.d_cpt = mkdiv(g.cpt); g.d_Wo = mkdiv(Wo); g.d_Ho = mkdiv(Ho); g.d_To = mkdiv(To);
       int64_t nb = (ntok + g.tpb - 1) / g.tpb;
       if (nb > 16384) nb = 16384;
+      if (dtype == DCC_BF16 && launch_im2col_row<float>(x, (bf16_t*)col, g, nullptr, nullptr, s)) return dcc_check_launch();
       if (dtype == DCC_BF16) hipLaunchKernelGGL((im2col3d_chunk_kernel<bf16_t, float>), dim3((unsigned)nb), dim3(256), 0, s, x, (bf16_t*)col, g, nullptr, nullptr);
       else hipLaunchKernelGGL((im2col3d_chunk_kernel<float, float>), dim3((unsigned)nb), dim3(256), 0, s, x, (float*)col, g, nullptr, nullptr);
       return dcc_check_launch();
@@ -1549,6 +1648,7 @@ extern "C" int dcc_im2col3d_u8(const uint8_t* x, const float* mean, const float*
   int64_t nb = (ntok + g.tpb - 1) / g.tpb;
   if (nb > 16384) nb = 16384;
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == DCC_BF16 && launch_im2col_row<uint8_t>(x, (bf16_t*)col, g, mean, stdv, s)) return dcc_check_launch();
   if (dtype == DCC_BF16) hipLaunchKernelGGL((im2col3d_chunk_kernel<bf16_t, uint8_t>), dim3((unsigned)nb), dim3(256), 0, s, x, (bf16_t*)col, g, mean, stdv);
   else hipLaunchKernelGGL((im2col3d_chunk_kernel<float, uint8_t>), dim3((unsigned)nb), dim3(256), 0, s, x, (float*)col, g, mean, stdv);
   return dcc_check_launch();

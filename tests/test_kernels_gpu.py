@@ -215,6 +215,32 @@ def test_patch_embed_fwd_bwd(dtype, tol, B, T, S):
     assert _rel(w.grad, wr.grad) < tol and _rel(b.grad, br.grad) < tol and _rel(c.grad, cr.grad) < tol
 
 
+@pytest.mark.parametrize("B,T,S", [(2, 16, 224), (3, 4, 112), (1, 6, 56)])
+@pytest.mark.parametrize("u8", [False, True])
+def test_im2col_rows_are_the_rounded_patches_exactly(B, T, S, u8):
+    """conv_proj operand (models/video_encoder.py:237 Conv3d k(3,7,7) s(2,4,4) p(1,3,3) as im2col): the bf16 column rows are the
+    input values rounded once, zero in the padding — exact equality with a torch unfold of the padded clip, for fp32 frames and
+    for uint8 frames normalised inside the gather (the LDS-staged row kernel and the chunk kernel must agree with it bit for bit)."""
+    from deepcoro_clip_amd import kernels as K
+
+    g = _gen(21)
+    kt, kh, kw, st, sh, sw, pt, ph, pw = 3, 7, 7, 2, 4, 4, 1, 3, 3
+    if u8:
+        raw = torch.randint(0, 256, (B, T, S, S, 3), generator=g, dtype=torch.uint8)
+        mean = torch.tensor([110.2, 98.7, 120.1]); std = torch.tensor([58.4, 61.2, 57.3])
+        vid = (raw.float() - mean) * (1.0 / std)
+        col = K.im2col3d(raw.cuda(), (kt, kh, kw), (st, sh, sw), (pt, ph, pw), 448, torch.bfloat16, norm=(mean.cuda(), std.cuda()))
+    else:
+        vid = torch.randn(B, T, S, S, 3, generator=g)
+        col = K.im2col3d(vid.cuda(), (kt, kh, kw), (st, sh, sw), (pt, ph, pw), 448, torch.bfloat16)
+    x = F.pad(vid.permute(0, 4, 1, 2, 3), (pw, pw, ph, ph, pt, pt))            # [B, 3, T+2, S+6, S+6]
+    p = x.unfold(2, kt, st).unfold(3, kh, sh).unfold(4, kw, sw)                # [B, 3, To, Ho, Wo, kt, kh, kw]
+    p = p.permute(0, 2, 3, 4, 5, 6, 7, 1).reshape(-1, kt * kh * kw * 3)        # (kt, kh, kw, c) column order
+    ref = torch.zeros(p.shape[0], 448)
+    ref[:, :441] = p
+    assert torch.equal(col.float().cpu(), ref.bfloat16().float())
+
+
 def test_rope_kernel_matches_reference_golden():
     """dcc_rope with the host-built tables vs models/rope_3d.py outputs recorded in tests/golden/rope.npz
     (a subset `tok` of the 393 tokens of an 8x7x7 grid, class token first)."""
