@@ -288,6 +288,58 @@ def linear(x, weight, bias=None, gelu: bool = False, residual=None):
     return LinearFn.apply(x, weight, bias, gelu, residual)
 
 
+class Linear2Fn(torch.autograd.Function):
+    """Two Linear layers of ONE input (the MViT blocks that change width: `attn.qkv` and the skip `project` both read
+    norm1(x), torchvision MultiscaleBlock.forward via models/video_encoder.py:232-253).  The backward chains the two
+    data-gradient GEMMs — the second adds the first through its residual epilogue — instead of leaving a [rows, C] add of
+    the two contributions to autograd (77 M elements in block 1)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        Kd = x.shape[-1]
+        x2 = _c(x).reshape(-1, Kd)
+        wc1, wc2 = wcast(w1, x.dtype), wcast(w2, x.dtype)
+        y1 = K.gemm(x2, wc1, bias=b1.detach() if b1 is not None else None)
+        y2 = K.gemm(x2, wc2, bias=b2.detach() if b2 is not None else None)
+        ctx.save_for_backward(x2, wc1, wc2)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.xshape = x.shape
+        return y1.reshape(*x.shape[:-1], w1.shape[0]), y2.reshape(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x2, wc1, wc2 = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        g1 = _c(dy1).reshape(-1, wc1.shape[0])
+        g2 = _c(dy2).reshape(-1, wc2.shape[0])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.gemm(g1, wc1, b_km=True)
+            dx = K.gemm(g2, wc2, b_km=True, resid=dx).reshape(ctx.xshape)
+        grads = []
+        for g, w, b, iw, ib in ((g1, w1, b1, 1, 2), (g2, w2, b2, 3, 4)):
+            dw = db = None
+            want_db = b is not None and ctx.needs_input_grad[ib]
+            if ctx.needs_input_grad[iw]:
+                if want_db:
+                    db = _grad_slots.take(b)
+                    if db is None:
+                        db = zeros_f32(g.shape[1], g.device)
+                dw = wgrad(g, x2, db, side=WGRAD_SIDE and grads_unset(w, b), out=_grad_slots.take(w))
+            elif want_db:
+                db = K.colsum(g)
+            grads += [dw, db]
+        return (dx, *grads)
+
+
+def linear2(x, w1, b1, w2, b2):
+    """(linear(x, w1, b1), linear(x, w2, b2)) with one fused data gradient; fp8 GEMM mode keeps the two separate layers."""
+    M = x.numel() // x.shape[-1]
+    if _fp8_ok(M, x.shape[-1], w1.shape[0], x.dtype) or _fp8_ok(M, x.shape[-1], w2.shape[0], x.dtype):
+        return linear(x, w1, b1), linear(x, w2, b2)
+    return Linear2Fn.apply(x, w1, b1, w2, b2)
+
+
 class MlpFn(torch.autograd.Function):
     """y = W2 gelu(W1 x + b1) + b2 [+ residual]; backward fuses gelu' into the fc2 data-gradient GEMM."""
 

@@ -145,7 +145,10 @@ class _Block(nn.Module):
             xn1, x = Fn.layernorm_skip(x, self.norm1.weight, self.norm1.bias, self.eps)
         else:
             xn1 = Fn.layernorm(x, self.norm1.weight, self.norm1.bias, self.eps)
-        qkv = Fn.linear(xn1, a.qkv.weight, a.qkv.bias)
+        if self.project is None:
+            qkv, xproj = Fn.linear(xn1, a.qkv.weight, a.qkv.bias), None
+        else:  # both read norm1(x): one autograd node, the data gradients chained through a residual epilogue
+            qkv, xproj = Fn.linear2(xn1, a.qkv.weight, a.qkv.bias, self.project.weight, self.project.bias)
         idx, inv, interp = self._idx(x.device)
         cfg = dict(B=Bp, N=N, H=a.num_heads, D=hd, thw=p["thw"], eps=self.eps, stride_q=p["stride_q"],
                    stride_kv=p["stride_kv"], scale=1.0 / math.sqrt(hd), idx=idx, inv=inv, rope=rope)
@@ -155,7 +158,7 @@ class _Block(nn.Module):
             a.pool_q.norm_act[0].weight, a.pool_q.norm_act[0].bias, a.pool_k.norm_act[0].weight,
             a.pool_k.norm_act[0].bias, a.pool_v.norm_act[0].weight, a.pool_v.norm_act[0].bias,
             rel[0], rel[1], rel[2], cfg)
-        xs = x if self.project is None else Fn.linear(xn1, self.project.weight, self.project.bias)
+        xs = x if self.project is None else xproj
         if math.prod(p["stride_q"]) > 1:
             ks = tuple(s + 1 if s > 1 else s for s in p["stride_q"])
             xs = Fn.pool_skip(xs, Bp, p["thw"], ks, p["stride_q"], tuple(k // 2 for k in ks))
