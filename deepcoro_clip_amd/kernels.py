@@ -12,7 +12,7 @@ import torch
 
 from . import _lib as L
 
-GEMM_BIAS, GEMM_GELU, GEMM_SAVE_PRE, GEMM_RESID, GEMM_DGELU, GEMM_ACCUM, GEMM_COLSUM_A = 1, 2, 4, 8, 16, 32, 64
+GEMM_BIAS, GEMM_GELU, GEMM_SAVE_PRE, GEMM_RESID, GEMM_DGELU, GEMM_ACCUM, GEMM_COLSUM_A, GEMM_STREAM_B = 1, 2, 4, 8, 16, 32, 64, 128
 import os as _os
 
 GEMM_VARIANT = int(_os.environ.get("DCC_GEMM_VARIANT", "0")) << 8  # tuning knob for A/B runs (see csrc/gemm.hip)
@@ -99,7 +99,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
          resid: torch.Tensor | None = None, aux: torch.Tensor | None = None, gelu: bool = False,
          save_pre: bool = False, dgelu: bool = False, out: torch.Tensor | None = None, accumulate: bool = False,
          out_dtype: torch.dtype | None = None, splitk: int = 1, alpha: float = 1.0,
-         colsum: torch.Tensor | None = None, stream: int | None = None) -> torch.Tensor:
+         colsum: torch.Tensor | None = None, stream: int | None = None, stream_b: bool = False) -> torch.Tensor:
     """C[m,n] = alpha * sum_k A(m,k) B(n,k) with fused epilogue.  `stream`: raw hipStream_t to launch on (default: torch's
     current stream).  `colsum` (fp32 [M], accumulated into; a_km only)
     receives sum_k A(m,k) — the bias gradient of a Linear layer for free inside its weight-gradient GEMM.
@@ -139,6 +139,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
     if colsum is not None:
         assert a_km and colsum.dtype == torch.float32 and colsum.numel() == M
         flags |= GEMM_COLSUM_A
+    if stream_b:  # operand B is a saved activation read exactly once: non-temporal loads (ring kernel; a hint elsewhere)
+        flags |= GEMM_STREAM_B
     flags |= GEMM_VARIANT
     # algorithmic HBM bytes: every operand once, the output once (read-modify-write when accumulating)
     osz = out.element_size()
