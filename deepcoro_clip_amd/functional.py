@@ -756,7 +756,7 @@ class PatchEmbedFn(torch.autograd.Function):
             dw2 = torch.zeros((Cout, Kp), **f32)
             K.gemm_batched(dy3[:, 1:], col, dw2, M=Cout, N=Kp, K=L_, lda=Cout, ldb=Kp, ldc=Kp, batch=Bp,
                            sA=(L_ + 1) * Cout, sB=L_ * Kp, sC=0, a_km=True, b_km=True, accumulate=True,
-                           splitk=max(1, min(64, 1024 // max(1, Bp))))
+                           splitk=max(1, min(64, 1024 // max(1, Bp))), stream_b=WGRAD_STREAM_X)
             dw = dw2[:, :Kc].reshape(Cout, kt, kh, kw, Cin).permute(0, 4, 1, 2, 3).contiguous()
         if ctx.needs_input_grad[2]:
             db_all = K.colsum(dy3.view(Bp * (L_ + 1), Cout))

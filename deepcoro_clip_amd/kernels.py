@@ -156,10 +156,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
 
 
 def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=None, a_km=False, b_km=False,
-                 alpha: float = 1.0, accumulate: bool = False, splitk: int = 1):
+                 alpha: float = 1.0, accumulate: bool = False, splitk: int = 1, stream_b: bool = False):
     """Raw batched form (base tensors + explicit strides); `a`/`b`/`out` only provide base pointers and dtypes."""
     L.require_cuda(a, b, out, bias)
-    flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_ACCUM if accumulate else 0) | GEMM_VARIANT
+    flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_ACCUM if accumulate else 0) | (GEMM_STREAM_B if stream_b else 0) | GEMM_VARIANT
     nbytes = batch * ((M * K + N * K) * a.element_size() + M * N * out.element_size() * (2 if accumulate else 1))
     with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * batch,
                 lambda: f"batched{batch} M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk}", nbytes):
