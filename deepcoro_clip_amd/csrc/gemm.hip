@@ -585,7 +585,7 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   if ((flags & GEMM_RESID) && !R) return DCC_ERR_ARG;
   if ((flags & (GEMM_SAVE_PRE | GEMM_DGELU)) && !aux) return DCC_ERR_ARG;
   if ((flags & GEMM_COLSUM_A) && (!colsum || !a_km || batch != 1)) return DCC_ERR_ARG;
-  if (splitk > 1 && (flags & 0xff & ~(GEMM_BIAS | GEMM_ACCUM | GEMM_COLSUM_A | GEMM_STREAM_B))) return DCC_ERR_ARG;  // non-linear epilogues need the full sum
+  if (splitk > 1 && (flags & 0xff & ~(GEMM_BIAS | GEMM_ACCUM | GEMM_COLSUM_A))) return DCC_ERR_ARG;  // non-linear epilogues need the full sum
   if (!aligned && in_dtype != DCC_F32) return DCC_ERR_UNSUPPORTED;  // bf16 callers always meet the chunk rules
   GemmParams p{A, B, C, bias, R, aux, colsum, lda, ldb, ldc, ldr, ldaux, sA, sB, sC, M, N, K, batch, splitk, alpha, (flags & 0xff) | (((flags >> 8) & 0xff) == 4 ? 0x1000 : 0) | (((flags >> 8) & 0xff) == 7 ? 0x2000 : 0), nullptr, nullptr, 0, 0};
   if ((int64_t)batch * splitk > 65535) return DCC_ERR_ARG;

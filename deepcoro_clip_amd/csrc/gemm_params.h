@@ -10,7 +10,6 @@
 #define GEMM_DGELU 16
 #define GEMM_ACCUM 32
 #define GEMM_COLSUM_A 64
-#define GEMM_STREAM_B 128  // operand B is read exactly once and is stale in the caches (a saved activation): non-temporal loads
 
 struct GemmParams {
   const void* A;

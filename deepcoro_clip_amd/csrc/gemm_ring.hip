@@ -113,7 +113,6 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
 
   if (loader) {
     // =============================================================================================== loader waves
-    const bool stream_b = (p.flags & GEMM_STREAM_B) != 0;   // wave-uniform: B is a saved activation nobody reads again
     // per-lane source offsets (bytes from the tile origin at k = 0) of this wave's four DMA pieces per operand
     int voffA[PPL], voffB[PPL];
     int kcA[PPL], kcB[PPL];  // k offset (elements) of this lane's chunk inside a K-step, k-contiguous operands only
@@ -172,8 +171,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
         const int vo = (!B_KM && k0 + kcB[j] >= p.K) ? OOB : voffB[j] + soB;
-        if (stream_b) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, st + TILE_B + (lw * PPL + j) * 1024), 16, vo, 0, 0, 2);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, st + TILE_B + (lw * PPL + j) * 1024), 16, vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, st + TILE_B + (lw * PPL + j) * 1024), 16, vo, 0, 0, 0);
       }
       if (bias_wave)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LDS_PTR(void, st + 2 * TILE_B + (lw & 1) * 256), 4, voffBias, 0, 0, 0);

@@ -177,8 +177,6 @@ def zeros_f32(shape, device) -> torch.Tensor:
 # will adopt the buffer without touching it) runs on a side stream, filling the launch gaps and partial last waves of the
 # data-gradient chain; the main stream re-joins it in an end-of-backward engine callback.
 WGRAD_SIDE = False
-# the saved activation of a weight-gradient GEMM is read once and left the caches long ago: non-temporal operand loads
-WGRAD_STREAM_X = os.environ.get("DCC_WGRAD_STREAM", "1") != "0"
 _WG = {"stream": None, "queued": False}
 
 
@@ -210,7 +208,7 @@ def wgrad(g2: torch.Tensor, x2: torch.Tensor, colsum: torch.Tensor | None = None
         except RuntimeError:  # not inside a backward pass: nobody would join the stream
             side = False
     if not side:
-        return K.gemm(g2, x2, a_km=True, b_km=True, out=out, accumulate=sk > 1, splitk=sk, colsum=colsum, stream_b=WGRAD_STREAM_X)
+        return K.gemm(g2, x2, a_km=True, b_km=True, out=out, accumulate=sk > 1, splitk=sk, colsum=colsum)
     if _WG["stream"] is None or _WG["stream"].device != g2.device:
         _WG["stream"] = torch.cuda.Stream(device=g2.device)
         _WG["event"] = torch.cuda.Event()
@@ -756,7 +754,7 @@ class PatchEmbedFn(torch.autograd.Function):
             dw2 = torch.zeros((Cout, Kp), **f32)
             K.gemm_batched(dy3[:, 1:], col, dw2, M=Cout, N=Kp, K=L_, lda=Cout, ldb=Kp, ldc=Kp, batch=Bp,
                            sA=(L_ + 1) * Cout, sB=L_ * Kp, sC=0, a_km=True, b_km=True, accumulate=True,
-                           splitk=max(1, min(64, 1024 // max(1, Bp))), stream_b=WGRAD_STREAM_X)
+                           splitk=max(1, min(64, 1024 // max(1, Bp))))
             dw = dw2[:, :Kc].reshape(Cout, kt, kh, kw, Cin).permute(0, 4, 1, 2, 3).contiguous()
         if ctx.needs_input_grad[2]:
             db_all = K.colsum(dy3.view(Bp * (L_ + 1), Cout))

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib as L
 
-GEMM_BIAS, GEMM_GELU, GEMM_SAVE_PRE, GEMM_RESID, GEMM_DGELU, GEMM_ACCUM, GEMM_COLSUM_A, GEMM_STREAM_B = 1, 2, 4, 8, 16, 32, 64, 128
+GEMM_BIAS, GEMM_GELU, GEMM_SAVE_PRE, GEMM_RESID, GEMM_DGELU, GEMM_ACCUM, GEMM_COLSUM_A = 1, 2, 4, 8, 16, 32, 64
 import os as _os
 
 GEMM_VARIANT = int(_os.environ.get("DCC_GEMM_VARIANT", "0")) << 8  # tuning knob for A/B runs (see csrc/gemm.hip)
@@ -99,7 +99,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
          resid: torch.Tensor | None = None, aux: torch.Tensor | None = None, gelu: bool = False,
          save_pre: bool = False, dgelu: bool = False, out: torch.Tensor | None = None, accumulate: bool = False,
          out_dtype: torch.dtype | None = None, splitk: int = 1, alpha: float = 1.0,
-         colsum: torch.Tensor | None = None, stream: int | None = None, stream_b: bool = False) -> torch.Tensor:
+         colsum: torch.Tensor | None = None, stream: int | None = None) -> torch.Tensor:
     """C[m,n] = alpha * sum_k A(m,k) B(n,k) with fused epilogue.  `stream`: raw hipStream_t to launch on (default: torch's
     current stream).  `colsum` (fp32 [M], accumulated into; a_km only)
     receives sum_k A(m,k) — the bias gradient of a Linear layer for free inside its weight-gradient GEMM.
@@ -139,8 +139,6 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
     if colsum is not None:
         assert a_km and colsum.dtype == torch.float32 and colsum.numel() == M
         flags |= GEMM_COLSUM_A
-    if stream_b:  # operand B is a saved activation read exactly once: non-temporal loads (ring kernel; a hint elsewhere)
-        flags |= GEMM_STREAM_B
     flags |= GEMM_VARIANT
     # algorithmic HBM bytes: every operand once, the output once (read-modify-write when accumulating)
     osz = out.element_size()
@@ -156,10 +154,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
 
 
 def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=None, a_km=False, b_km=False,
-                 alpha: float = 1.0, accumulate: bool = False, splitk: int = 1, stream_b: bool = False):
+                 alpha: float = 1.0, accumulate: bool = False, splitk: int = 1):
     """Raw batched form (base tensors + explicit strides); `a`/`b`/`out` only provide base pointers and dtypes."""
     L.require_cuda(a, b, out, bias)
-    flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_ACCUM if accumulate else 0) | (GEMM_STREAM_B if stream_b else 0) | GEMM_VARIANT
+    flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_ACCUM if accumulate else 0) | GEMM_VARIANT
     nbytes = batch * ((M * K + N * K) * a.element_size() + M * N * out.element_size() * (2 if accumulate else 1))
     with _timed("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * batch,
                 lambda: f"batched{batch} M{M} N{N} K{K} {'T' if a_km else 'N'}{'T' if b_km else 'N'} sk{splitk}", nbytes):
