@@ -107,3 +107,15 @@ def call(name: str, *args) -> None:
     rc = getattr(lib(), name)(*args)
     if rc != 0:
         raise DccError(f"{name} failed with {_ERR.get(rc, rc)}")
+
+
+def try_call(name: str, *args) -> bool:
+    """For SPECIALISED entry points that have a general HIP counterpart (fused pool + LayerNorm, fused rel-pos forward): False
+    when the kernel reports DCC_ERR_UNSUPPORTED for this shape, so that the caller launches the general HIP kernels instead;
+    every other failure raises.  (Still no CPU fallback: both alternatives are entries of the same library.)"""
+    rc = getattr(lib(), name)(*args)
+    if rc == -3:
+        return False
+    if rc != 0:
+        raise DccError(f"{name} failed with {_ERR.get(rc, rc)}")
+    return True

@@ -577,9 +577,11 @@ class MvitAttnCoreFn(torch.autograd.Function):
                                                       ("k", wk, gk, bk, Kf.view(-1, DQK)[:, :D]),
                                                       ("v", wv, gv, bv, Vn.view(-1, D)))):
             with br.stream(i):
+                fused = None
                 if FUSED_POOL_LN and K.pool_ln_supported(qkv5[:, :, i], geo[name]):
-                    conv[name], m_, r_ = K.pool_ln_fwd(qkv5[:, :, i], geo[name], w.detach().reshape(D, 27), gam.detach(),
-                                                       bet.detach(), eps, dst)
+                    fused = K.pool_ln_fwd(qkv5[:, :, i], geo[name], w.detach().reshape(D, 27), gam.detach(), bet.detach(), eps, dst)
+                if fused is not None:
+                    conv[name], m_, r_ = fused
                 else:
                     conv[name], _ = K.pool_fwd(qkv5[:, :, i], geo[name], w.detach().reshape(D, 27))
                     _, m_, r_ = K.layernorm_fwd(conv[name].view(-1, D), gam.detach(), bet.detach(), eps, out=dst)
@@ -599,8 +601,8 @@ class MvitAttnCoreFn(torch.autograd.Function):
         dims_q = K.relpos_dims(B, H, D, A, Lp, q_thw, k_thw, lens)
         fused_rel = FUSED_RELPOS and K.relpos_fused_supported(Qf, D, A, k_thw, q_thw, Lp)
         if fused_rel:  # products only against the table rows each query uses, straight from q: no P tensor
-            K.relpos_aug_fwd(Qf, Rcat, idx, dims_q, scale)
-        else:
+            fused_rel = K.relpos_aug_fwd(Qf, Rcat, idx, dims_q, scale)
+        if not fused_rel:
             q2d = Qf.view(-1, DQK)[:, :D]
             P = K.gemm(q2d, Rcat)
             K.relpos_gather(Qf, P, idx, dims_q, scale)

@@ -341,7 +341,7 @@ def pool_ln_fwd(x: torch.Tensor, g: PoolGeom, weight: torch.Tensor, gamma: torch
                 out: torch.Tensor):
     """Depthwise-conv pool of x ([B, N_in, H, 96] view) + LayerNorm over the head dimension in one launch.
     out: [B*N_out*H, 96] rows (row stride free, e.g. the first 96 columns of the [.., DQK] attention operand).
-    Returns (conv [B, N_out, H, 96], mean, rstd)."""
+    Returns (conv [B, N_out, H, 96], mean, rstd), or None when the shape is outside the kernel's domain."""
     L.require_cuda(x, weight, gamma, beta, out)
     assert x.shape == (g.B, g.n_in, g.H, g.C) and pool_ln_supported(x, g)
     rows = g.B * g.n_out * g.H
@@ -351,8 +351,9 @@ def pool_ln_fwd(x: torch.Tensor, g: PoolGeom, weight: torch.Tensor, gamma: torch
     conv = torch.empty((g.B, g.n_out, g.H, g.C), device=x.device, dtype=x.dtype)
     mean = torch.empty(rows, device=x.device, dtype=torch.float32)
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-    L.call("dcc_pool_ln_fwd", L.ptr(x), L.ptr(conv), L.ptr(out), out.stride(0), L.ptr(weight), L.ptr(gamma), L.ptr(beta),
-           L.ptr(mean), L.ptr(rstd), g.dims(), _pool_strides(x, conv), float(eps), L.dt(x), L.stream())
+    if not L.try_call("dcc_pool_ln_fwd", L.ptr(x), L.ptr(conv), L.ptr(out), out.stride(0), L.ptr(weight), L.ptr(gamma), L.ptr(beta),
+                      L.ptr(mean), L.ptr(rstd), g.dims(), _pool_strides(x, conv), float(eps), L.dt(x), L.stream()):
+        return None  # outside the fused kernel's index range (very large batches): the caller runs conv + LayerNorm
     return conv, mean, rstd
 
 
@@ -436,11 +437,12 @@ def relpos_fused_supported(Qf: torch.Tensor, D: int, A: int, k_thw, q_thw=None, 
 
 
 def relpos_aug_fwd(Qf, Rcat, idx, dims, scale):
-    """Qf[..., D:] = rel-pos inner products of Qf[..., :D] against the table rows each query uses (no P tensor)."""
+    """Qf[..., D:] = rel-pos inner products of Qf[..., :D] against the table rows each query uses (no P tensor).
+    False when the shape is outside the kernel's domain (the caller then runs the GEMM + gather)."""
     L.require_cuda(Qf, Rcat)
     assert Rcat.is_contiguous() and Rcat.dtype == Qf.dtype
-    L.call("dcc_relpos_aug_fwd", L.ptr(Qf), L.ptr(Rcat), L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims,
-           _i64(_strides3(Qf)), float(scale), L.dt(Qf), L.stream())
+    return L.try_call("dcc_relpos_aug_fwd", L.ptr(Qf), L.ptr(Rcat), L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims,
+                      _i64(_strides3(Qf)), float(scale), L.dt(Qf), L.stream())
 
 
 def relpos_kaug(Kf, dims):

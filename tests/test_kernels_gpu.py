@@ -168,6 +168,26 @@ def test_fused_pool_layernorm_fwd(stride, thw, H, B, ldo):
     assert _rel(mean.cpu(), conv.float().cpu().mean(-1).reshape(-1)) < 1e-4
 
 
+def test_specialised_entries_report_unsupported_without_raising():
+    """The fused pool + LayerNorm entry has a general HIP counterpart: outside its domain it returns DCC_ERR_UNSUPPORTED, which
+    `try_call` turns into False (the caller then launches conv + LayerNorm); argument errors still raise."""
+    from deepcoro_clip_amd import _lib as L
+    from deepcoro_clip_amd import kernels as K
+    from deepcoro_clip_amd._lib import DccError
+
+    geo = K.PoolGeom(1, 1, 96, (2, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1), True)
+    x = torch.randn(1, geo.n_in, 1, 96, device="cuda")          # fp32: not in the fused kernel's domain
+    y = torch.empty(1, geo.n_out, 1, 96, device="cuda")
+    o = torch.empty(geo.n_out, 96, device="cuda")
+    w = torch.randn(96, 27, device="cuda"); g_ = torch.ones(96, device="cuda"); b_ = torch.zeros(96, device="cuda")
+    m = torch.empty(geo.n_out, device="cuda"); r = torch.empty(geo.n_out, device="cuda")
+    args = (L.ptr(x), L.ptr(y), L.ptr(o), 96, L.ptr(w), L.ptr(g_), L.ptr(b_), L.ptr(m), L.ptr(r), geo.dims(),
+            K._pool_strides(x, y), 1e-6, L.dt(x), L.stream())
+    assert L.try_call("dcc_pool_ln_fwd", *args) is False
+    with pytest.raises(DccError):
+        L.try_call("dcc_pool_ln_fwd", None, *args[1:])
+
+
 @pytest.mark.parametrize("C", [192, 768])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool_skip_fwd_bwd(dtype, C):
