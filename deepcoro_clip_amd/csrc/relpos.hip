@@ -328,6 +328,219 @@ __global__ __launch_bounds__(256) void relpos_aug_fwd_kernel(bf16_t* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------- fused backward on the matrix cores
+// One kernel instead of scatter + two GEMMs, and no [rows, L] dP tensor in HBM.  A block walks tiles of 64 consecutive
+// (clip, token, head) rows: it builds the tile's dP [64][L] in LDS exactly as the scatter kernel would write it (zeros, then the
+// k_h + k_w + k_t augmentation gradients of every row at their table rows, scaled and rounded to bf16), then
+//   dq [64][96]  = dP . Rcat + dQf[:, :96]      (3 waves, one 32-column slab each; tables resident in LDS),
+//   dR [L][96]  += dP^T . q                      (all 4 waves; accumulators stay in registers across the block's tiles),
+// both on v_mfma_f32_32x32x16_bf16 with fragments read straight from the LDS images (row-major dP serves product 1 as a
+// k-contiguous operand and product 2 as a k-major operand through ds_read_tr16_b64).  Each block's dR goes to a workspace that
+// relpos_fold_kernel sums.  Same arithmetic as the three-kernel path (bf16 dP, fp32 accumulation).
+// (An earlier VALU version of this backward used LDS float atomics for the table gradient and was 6-30x slower than the GEMM path.)
+__device__ __forceinline__ bf16x8 rfrag_kc(const char* base, int pitch, int r0, int s, int lane) {
+  return *reinterpret_cast<const bf16x8*>(base + (r0 + (lane & 31)) * pitch + (16 * s + 8 * (lane >> 5)) * 2);
+}
+// LDS rows = k, columns = the m / n index (c0 + 32 of them), transposing reads
+__device__ __forceinline__ bf16x8 rfrag_km(const char* base, int pitch, int c0, int s, int lane) {
+  const int h = lane >> 5, i = lane & 15, q = i >> 2, pp = i & 3, g = (lane >> 4) & 1;
+  bf16x8 f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int krow = 16 * s + 8 * h + 4 * half + q;
+    const char* p = base + krow * pitch + (c0 + 16 * g + 4 * pp) * 2;
+    const bf16x4 tb = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p)));
+    f[4 * half + 0] = tb[0]; f[4 * half + 1] = tb[1]; f[4 * half + 2] = tb[2]; f[4 * half + 3] = tb[3];
+  }
+  return f;
+}
+
+#ifdef RB_PROF
+__device__ unsigned long long g_rbprof[8];
+#define RBT() __builtin_amdgcn_s_memtime()
+#define RBP(i, t0) do { if (tid == 0) atomicAdd(&g_rbprof[i], RBT() - (t0)); } while (0)
+#else
+#define RBT() 0ull
+#define RBP(i, t0) do { } while (0)
+#endif
+template <int NMT>   // 32-row slabs of dR per wave: ceil(LPp / 32 / 4)
+__global__ __launch_bounds__(256) void relpos_bwd_mfma_kernel(const bf16_t* __restrict__ dQf, const bf16_t* __restrict__ Qf,
+                                                              bf16_t* __restrict__ dq, const bf16_t* __restrict__ Rcat,
+                                                              float* __restrict__ ws, const int* __restrict__ idx_h,
+                                                              const int* __restrict__ idx_w, const int* __restrict__ idx_t,
+                                                              RelGeom g, RelDiv dv, float inv_scale, unsigned rows, int LPp,
+                                                              int dpp, unsigned ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char rlds[];
+  char* Rs = rlds;                       // [LPp][192 B]   stacked tables, zero rows past g.L
+  char* dP = Rs + LPp * 192;             // [64][dpp]
+  char* Qs = dP + 64 * dpp;              // [64][192 B]   q rows of the tile
+  constexpr int RZP = 208;               // residual tile row pitch (192 + 16: the epilogue's 8-byte reads stay conflict-light)
+  char* Rz = Qs + 64 * 192;              // [64][RZP]     dQf[:, :96] rows of the tile
+  int* ih = reinterpret_cast<int*>(Rz + 64 * RZP);
+  int* iw = ih + g.qh * g.kh;
+  int* it = iw + g.qw * g.kw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  const unsigned long long tp0 = RBT();
+  for (int i = tid; i < LPp * 12; i += 256) {
+    const int l = i / 12;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    reinterpret_cast<u32x4*>(Rs)[i] = l < g.L ? reinterpret_cast<const u32x4*>(Rcat)[i] : z;
+  }
+  for (int i = tid; i < g.qh * g.kh; i += 256) ih[i] = idx_h[i];
+  for (int i = tid; i < g.qw * g.kw; i += 256) iw[i] = idx_w[i] + g.Lh;
+  for (int i = tid; i < g.qt * g.kt; i += 256) it[i] = idx_t[i] + g.Lh + g.Lw;
+  const int Nq = g.qt * g.qh * g.qw + g.has_cls;
+  const int areal = g.kh + g.kw + g.kt;
+  f32x16 dR[NMT][3];
+#pragma unroll
+  for (int i = 0; i < NMT; ++i)
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dR[i][n][e] = 0.0f;
+  const int r = tid >> 2, part = tid & 3;     // this thread's tile row and quarter
+  const int zunits = 64 * dpp / 16;
+  const int apq = g.A >> 2;                   // this thread's share of a row's augmentation gradients: A/4 = 8 or 16 columns
+  const u32x4 z4 = {0u, 0u, 0u, 0u};
+  // The global loads of tile i+1 (q row, residual row, augmentation gradients: 8 x 16 bytes per thread) are issued at the START
+  // of tile i, right after tile i's registers went to LDS, so a whole tile of work covers their latency (in-kernel timers: with
+  // the loads issued mid-tile, and the residual fetched in the epilogue, three exposed memory waits were 90 % of a tile).
+  u32x4 pq[3], pz[3], pg[2];
+  RowPos pp_;
+  bool plive;
+  auto prefetch = [&](unsigned tile) {
+    const unsigned row = tile * 64u + r;
+    plive = tile < ntiles && row < rows;
+    pp_ = row_pos(plive ? row : 0u, g, dv, Nq);
+    const int64_t off = pp_.b * g.sb + (int64_t)pp_.n * g.sn + pp_.hd * g.sh;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      pq[c] = plive ? reinterpret_cast<const u32x4*>(Qf + off)[part * 3 + c] : z4;
+      pz[c] = plive ? reinterpret_cast<const u32x4*>(dQf + off)[part * 3 + c] : z4;
+    }
+    pg[0] = plive ? reinterpret_cast<const u32x4*>(dQf + off + g.D + part * apq)[0] : z4;
+    pg[1] = (plive && apq > 8) ? reinterpret_cast<const u32x4*>(dQf + off + g.D + part * apq)[1] : z4;
+  };
+  prefetch(blockIdx.x);
+  RBP(0, tp0);
+  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const unsigned long long t1 = RBT();
+    __syncthreads();   // the previous tile's fragment reads are done (and, first time, the tables are staged)
+    RBP(1, t1);
+    const unsigned long long t2 = RBT();
+    const RowPos p = pp_;
+    const bool live = plive;
+    const u32x4 gr[2] = {pg[0], pg[1]};
+    for (int i = tid; i < zunits; i += 256) reinterpret_cast<u32x4*>(dP)[i] = z4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      reinterpret_cast<u32x4*>(Qs + r * 192)[part * 3 + c] = pq[c];
+      reinterpret_cast<u32x4*>(Rz + r * RZP)[part * 3 + c] = pz[c];
+    }
+    prefetch(tile + gridDim.x);
+    __syncthreads();   // zeros are in place
+    RBP(2, t2);
+    const unsigned long long t3 = RBT();
+    if (live && p.tok) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (e >= apq) break;
+        const int j = part * apq + e;
+        if (j < areal) {
+          const int ax = (j >= g.kh) + (j >= g.kh + g.kw);
+          const int l = ax == 0 ? ih[p.hh * g.kh + j] : (ax == 1 ? iw[p.w * g.kw + (j - g.kh)] : it[p.t * g.kt + (j - g.kh - g.kw)]);
+          const unsigned v = gr[e >> 3][(e >> 1) & 3];
+          const float gf = (e & 1) ? __builtin_bit_cast(float, v & 0xffff0000u) : __builtin_bit_cast(float, v << 16);
+          *reinterpret_cast<bf16_t*>(dP + r * dpp + l * 2) = (bf16_t)(gf * inv_scale);
+        }
+      }
+    }
+    __syncthreads();   // dP, Qs and the residual tile are complete
+    RBP(3, t3);
+    const unsigned long long t4 = RBT();
+    // ---- product 2: dR[l][c] += sum_rows dP[row][l] q[row][c]   (k = the 64 tile rows)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 fq[3];
+#pragma unroll
+      for (int n = 0; n < 3; ++n) fq[n] = rfrag_km(Qs, 192, 32 * n, s, lane);
+#pragma unroll
+      for (int i = 0; i < NMT; ++i) {
+        const int mt = wave + 4 * i;
+        if (32 * mt < LPp) {   // wave-uniform
+          const bf16x8 fa = rfrag_km(dP, dpp, 32 * mt, s, lane);
+#pragma unroll
+          for (int n = 0; n < 3; ++n) dR[i][n] = mma16(fa, fq[n], dR[i][n]);
+        }
+      }
+    }
+    RBP(4, t4);
+    const unsigned long long t5 = RBT();
+    // ---- product 1: dq[row][c] = sum_l dP[row][l] Rcat[l][c] + residual   (waves 0..2: 32 columns each; C^T form, lanes = rows)
+    if (wave < 3) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+      for (int s = 0; s < LPp / 16; ++s) {
+        const bf16x8 fb = rfrag_km(Rs, 192, 32 * wave, s, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = mma16(fb, rfrag_kc(dP, dpp, 32 * i, s, lane), acc[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned orow = tile * 64u + 32 * i + (lane & 31);
+        if (orow < rows) {
+          const char* res = Rz + (32 * i + (lane & 31)) * RZP + (32 * wave + 4 * h) * 2;
+          bf16_t* dst = dq + (int64_t)orow * g.D + 32 * wave + 4 * h;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + 16 * g4);
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[i][4 * g4 + e] + (float)rv[e]);
+            *reinterpret_cast<bf16x4*>(dst + 8 * g4) = o;
+          }
+        }
+      }
+    }
+    RBP(5, t5);
+  }
+  const unsigned long long t6 = RBT();
+  // ---- this block's table gradient -> workspace [block][g.L][96]
+  float* out = ws + (int64_t)blockIdx.x * g.L * 96;
+#pragma unroll
+  for (int i = 0; i < NMT; ++i) {
+    const int mt = wave + 4 * i;
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = 32 * mt + acc_row(e, h);
+        if (m < g.L) out[m * 96 + 32 * n + (lane & 31)] = dR[i][n][e];
+      }
+  }
+  RBP(6, t6);
+}
+
+// out[i] += sum_b ws[b][i]  (i over n4 float4 columns): block = 64 columns x 4 row lanes, gridDim.y row slices, the four lanes
+// fold through LDS and every slice adds its sum with one atomic per element.
+__global__ __launch_bounds__(256) void relpos_fold_kernel(const float* __restrict__ ws, float* __restrict__ out, int nb, int n4) {
+  __shared__ f32x4 red[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (c < n4)
+    for (int b = blockIdx.y * 4 + rl; b < nb; b += gridDim.y * 4) s += reinterpret_cast<const f32x4*>(ws)[(int64_t)b * n4 + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < n4) {
+    s = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(out + 4 * c + e, s[e]);
+  }
+}
+
 inline unsigned gsb(int64_t n) {
   int64_t b = (n + 255) / 256;
   if (b > 16384) b = 16384;
@@ -439,3 +652,57 @@ extern "C" int dcc_relpos_aug_fwd(void* Qf, const void* Rcat, const int* idx_h, 
   hipLaunchKernelGGL(k2, dim3((unsigned)nb), dim3(256), lds, st, (bf16_t*)Qf, (const bf16_t*)Rcat, idx_h, idx_w, idx_t, g, dv, 1.0f / scale, (unsigned)rows);
   return dcc_check_launch();
 }
+
+// Fused backward: dq [B*Nq*H][D] = dQf[:, :D] + (dQf[:, D:] / scale) against the table rows; dRcat [L][D] fp32 is ACCUMULATED
+// into (the gradient of the three stacked tables); ws: scratch of max_blocks * L * D floats for the per-block partials (no
+// initialisation needed).  = dcc_relpos_scatter + dcc_gemm (dP Rcat + residual) + dcc_gemm (dP^T q).
+extern "C" int dcc_relpos_aug_bwd(const void* dQf, const void* Qf, void* dq, const void* Rcat, float* dRcat, float* ws,
+                                  int max_blocks, const int* idx_h, const int* idx_w, const int* idx_t, const int* dims,
+                                  const int64_t* strides, float scale, int dtype, void* stream) {
+  if (!dQf || !Qf || !dq || !Rcat || !dRcat || !ws || !idx_h || !idx_w || !idx_t || !dims || !strides || max_blocks < 1) return DCC_ERR_ARG;
+  if (dtype != DCC_BF16) return DCC_ERR_UNSUPPORTED;
+  RelGeom g = mk(dims, strides);
+  if (g.D != 96 || (g.A != 32 && g.A != 64) || g.A < g.kh + g.kw + g.kt || g.L < g.Lh + g.Lw + g.Lt || (g.L % 8)) return DCC_ERR_UNSUPPORTED;
+  if ((g.sb % 8) || (g.sn % 8) || (g.sh % 8) || (((uintptr_t)dQf) & 15) || (((uintptr_t)Qf) & 15) || (((uintptr_t)dq) & 7) ||
+      (((uintptr_t)Rcat) & 15) || (((uintptr_t)ws) & 15))
+    return DCC_ERR_UNSUPPORTED;
+  const int64_t rows = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H;
+  const int LPp = (g.L + 31) & ~31;
+  if (LPp > 256 || rows >= (1LL << 31)) return DCC_ERR_UNSUPPORTED;
+  const int dpp = LPp * 2 + (((LPp / 8) & 1) ? 0 : 16);   // row pitch of dP: an odd number of 16-byte units
+  const size_t lds = (size_t)LPp * 192 + (size_t)64 * dpp + 64 * 192 + 64 * 208 + (size_t)(g.qh * g.kh + g.qw * g.kw + g.qt * g.kt) * 4;
+  if (lds > 150 * 1024) return DCC_ERR_UNSUPPORTED;
+  const int64_t ntiles = (rows + 63) / 64;
+  const int per_cu = (int)((160 * 1024) / lds);
+  int64_t nb = 256LL * (per_cu > 3 ? 3 : per_cu);   // persistent: the tables are staged once per block
+  if (nb > ntiles) nb = ntiles;
+  if (nb > max_blocks) nb = max_blocks;
+  hipStream_t st = (hipStream_t)stream;
+  const RelDiv dv{mkdiv(g.H), mkdiv(g.qt * g.qh * g.qw + g.has_cls), mkdiv(g.qw * g.qh), mkdiv(g.qw), mkdiv(1), mkdiv(1)};
+  auto k1 = relpos_bwd_mfma_kernel<1>;
+  auto k2 = relpos_bwd_mfma_kernel<2>;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+      return DCC_ERR_LAUNCH;
+    configured = true;
+  }
+  if (LPp <= 128) hipLaunchKernelGGL(k1, dim3((unsigned)nb), dim3(256), lds, st, (const bf16_t*)dQf, (const bf16_t*)Qf, (bf16_t*)dq, (const bf16_t*)Rcat, ws, idx_h, idx_w, idx_t, g, dv, 1.0f / scale, (unsigned)rows, LPp, dpp, (unsigned)ntiles);
+  else hipLaunchKernelGGL(k2, dim3((unsigned)nb), dim3(256), lds, st, (const bf16_t*)dQf, (const bf16_t*)Qf, (bf16_t*)dq, (const bf16_t*)Rcat, ws, idx_h, idx_w, idx_t, g, dv, 1.0f / scale, (unsigned)rows, LPp, dpp, (unsigned)ntiles);
+  int rc = dcc_check_launch();
+  if (rc) return rc;
+  const int n4 = g.L * 24;
+  hipLaunchKernelGGL(relpos_fold_kernel, dim3((n4 + 63) / 64, 8), dim3(256), 0, st, ws, dRcat, (int)nb, n4);
+  return dcc_check_launch();
+}
+
+#ifdef RB_PROF
+extern "C" int dcc_relpos_prof_read(unsigned long long* out8, int reset) {
+  unsigned long long h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rbprof), sizeof(h)) != hipSuccess) return DCC_ERR_LAUNCH;
+  for (int i = 0; i < 8; ++i) out8[i] = h[i];
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rbprof), z, sizeof(z)) != hipSuccess) return DCC_ERR_LAUNCH; }
+  return DCC_OK;
+}
+#endif

@@ -544,6 +544,8 @@ FUSED_POOL_LN = os.environ.get("DCC_FUSED_POOL_LN", "1") != "0"
 # forward rel-pos inner products without the [rows, L] P tensor where that is faster (dcc_relpos_aug_fwd: bf16, 7 x 7 key
 # grids); DCC_FUSED_RELPOS=0 keeps the stacked-table GEMM + gather everywhere
 FUSED_RELPOS = os.environ.get("DCC_FUSED_RELPOS", "1") != "0"
+# rel-pos backward as one MFMA kernel that builds dP per 64-row tile in LDS (dcc_relpos_aug_bwd) instead of scatter + two GEMMs
+FUSED_RELPOS_BWD = os.environ.get("DCC_FUSED_RELPOS_BWD", "1") != "0"
 
 
 class MvitAttnCoreFn(torch.autograd.Function):
@@ -668,12 +670,19 @@ class MvitAttnCoreFn(torch.autograd.Function):
         # dP (scatter of the augmentation columns), then two GEMMs: d tables = dP^T q, dq = dP Rcat + dQf[:, :D]
         dims_q = K.relpos_dims(B, H, D, A, Lp, geo["q"].out_thw, geo["k"].out_thw, lens)
         rows_q = B * Nq * H
-        dP = torch.empty((rows_q, Lp), device=dev, dtype=dt)
-        K.relpos_scatter(dQf, dP, cfg["inv"], dims_q, scale)
-        q2d = Qf.view(-1, DQK)[:, :D]
-        drel_cat = wgrad(dP, q2d)
-        dq = K.gemm(dP, Rcat, b_km=True, resid=dQf.view(-1, DQK)[:, :D]).view(B, Nq, H, D)
-        del dP
+        dq = None
+        # dP built and consumed in LDS (no [rows, L] tensor) where that is faster than scatter + two GEMMs (tools/relpos_bench.py:
+        # every 32-column augmentation, and the 64-column one from 300 k rows up)
+        if FUSED_RELPOS_BWD and dt == torch.bfloat16 and D == 96 and (A == 32 or rows_q >= 300000):
+            drel_cat = zeros_f32((Lp, D), dev)
+            dq = K.relpos_aug_bwd(dQf, Qf, Rcat, cfg["idx"], dims_q, scale, drel_cat)
+        if dq is None:
+            dP = torch.empty((rows_q, Lp), device=dev, dtype=dt)
+            K.relpos_scatter(dQf, dP, cfg["inv"], dims_q, scale)
+            q2d = Qf.view(-1, DQK)[:, :D]
+            drel_cat = wgrad(dP, q2d)
+            dq = K.gemm(dP, Rcat, b_km=True, resid=dQf.view(-1, DQK)[:, :D]).view(B, Nq, H, D)
+            del dP
         drel = (drel_cat[:lens[0]], drel_cat[lens[0]:lens[0] + lens[1]], drel_cat[lens[0] + lens[1]:sum(lens)])
         if rope is not None:
             K.rope(dq, dq, rope["cos_q"], rope["sin_q"], backward=True)

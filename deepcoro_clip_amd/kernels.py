@@ -445,6 +445,29 @@ def relpos_aug_fwd(Qf, Rcat, idx, dims, scale):
                       _i64(_strides3(Qf)), float(scale), L.dt(Qf), L.stream())
 
 
+_RELPOS_WS: dict = {}
+_RELPOS_MAX_BLOCKS = 768
+
+
+def relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dRcat):
+    """dq [B, Nq, H, D] = dQf[..., :D] + table path of dQf[..., D:]; dRcat [L, D] fp32 accumulated into.  None when the shape
+    is outside the fused kernel's domain (the caller then runs scatter + the two GEMMs)."""
+    L.require_cuda(dQf, Qf, Rcat, dRcat)
+    assert Rcat.is_contiguous() and dQf.stride() == Qf.stride() and dRcat.dtype == torch.float32 and dRcat.is_contiguous()
+    B, Nq, H, _ = dQf.shape
+    D = Rcat.shape[1]
+    dq = torch.empty((B, Nq, H, D), device=dQf.device, dtype=dQf.dtype)
+    n = _RELPOS_MAX_BLOCKS * Rcat.shape[0] * D
+    key = (dQf.device.index, n, L.stream())
+    ws = _RELPOS_WS.get(key)
+    if ws is None:
+        ws = _RELPOS_WS[key] = torch.empty(n, device=dQf.device, dtype=torch.float32)
+    ok = L.try_call("dcc_relpos_aug_bwd", L.ptr(dQf), L.ptr(Qf), L.ptr(dq), L.ptr(Rcat), L.ptr(dRcat), L.ptr(ws),
+                    _RELPOS_MAX_BLOCKS, L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims, _i64(_strides3(dQf)), float(scale),
+                    L.dt(dQf), L.stream())
+    return dq if ok else None
+
+
 def relpos_kaug(Kf, dims):
     L.require_cuda(Kf)
     L.call("dcc_relpos_kaug", L.ptr(Kf), dims, _i64(_strides3(Kf)), L.dt(Kf), L.stream())

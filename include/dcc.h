@@ -114,6 +114,13 @@ int dcc_relpos_kaug(void* Kf, const int* dims, const int64_t* strides, int dtype
  * = dcc_gemm(q, Rcat) + dcc_relpos_gather.  DCC_ERR_UNSUPPORTED outside that domain. */
 int dcc_relpos_aug_fwd(void* Qf, const void* Rcat, const int* idx_h, const int* idx_w, const int* idx_t, const int* dims,
                        const int64_t* strides, float scale, int dtype, void* stream);
+/* Fused backward on the matrix cores (bf16, D == 96, A in {32, 64}, L <= 256): per 64-row tile the dP the scatter kernel would
+ * write is built in LDS and consumed there: dq [B*N*H][D] = dP Rcat + dQf[:, :D], dRcat [L][D] fp32 += dP^T q — i.e.
+ * dcc_relpos_scatter + the two dcc_gemm calls without the [rows, L] tensor.  ws: fp32 scratch [max_blocks * L * D] (per-block
+ * partial table gradients, no initialisation needed).  DCC_ERR_UNSUPPORTED outside that domain. */
+int dcc_relpos_aug_bwd(const void* dQf, const void* Qf, void* dq, const void* Rcat, float* dRcat, float* ws, int max_blocks,
+                       const int* idx_h, const int* idx_w, const int* idx_t, const int* dims, const int64_t* strides,
+                       float scale, int dtype, void* stream);
 
 /* ---- LayerNorm (csrc/norm.hip): nn.LayerNorm in MViT blocks / Pool.norm_act / BERT / aggregator /
  * attention pool (models/video_aggregator.py:15,24,99; models/attention_pool.py:53,94). */

@@ -68,3 +68,62 @@ def test_fused_relpos_matches_gemm_path_and_reference(B, H, q_thw, k_thw):
     assert (got - ref).abs().max().item() / den < 1e-2           # one bf16 rounding of fp32 dot products
     assert (Qb[..., D:].float().cpu() - ref).abs().max().item() / den < 2e-2   # the old path rounds twice
     assert torch.all(got[:, 0] == 0) and torch.all(got[..., kh + kw + kt:] == 0)
+
+
+@pytest.mark.parametrize("B,H,q_thw,k_thw", [(2, 4, (8, 14, 14), (8, 7, 7)), (1, 2, (8, 28, 28), (8, 14, 14)),
+                                             (3, 8, (8, 7, 7), (8, 14, 14)), (1, 1, (8, 56, 56), (8, 7, 7)),
+                                             (2, 8, (8, 7, 7), (8, 7, 7)), (1, 4, (4, 14, 14), (4, 14, 14))])
+def test_fused_relpos_backward_matches_gemm_path_and_reference(B, H, q_thw, k_thw):
+    """dcc_relpos_aug_bwd (dP built per tile in LDS, both products on the matrix cores) against scatter + two GEMMs and against
+    an fp32 restatement: dq = dQf[:, :D] + sum_j g_j R[l_j] / scale, dR[l] = sum over (row, j -> l) g_j q_row / scale."""
+    from deepcoro_clip_amd import functional as Fn
+    from deepcoro_clip_amd import kernels as K
+
+    D = 96
+    g = torch.Generator().manual_seed(9)
+    A = Fn.relpos_aug_width(k_thw)
+    DQK = D + A
+    Nq = q_thw[0] * q_thw[1] * q_thw[2] + 1
+    idx, inv, tabs = _tables(q_thw, k_thw, D, g)
+    lens = tuple(t.shape[0] for t in tabs)
+    Lp = 8 * ((sum(lens) + 7) // 8)
+    Rcat = torch.zeros(Lp, D, dtype=torch.bfloat16)
+    Rcat[:sum(lens)] = torch.cat(tabs, 0)
+    Rcat = Rcat.cuda()
+    scale = 1.0 / D ** 0.5
+    dims = K.relpos_dims(B, H, D, A, Lp, q_thw, k_thw, lens)
+    Qf = (torch.randn(B, Nq, H, DQK, generator=g) * 0.5).bfloat16().cuda()
+    dQf = (torch.randn(B, Nq, H, DQK, generator=g) * 0.5).bfloat16().cuda()
+    dR = torch.zeros(Lp, D, device="cuda")
+    dq = K.relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dR)
+    assert dq is not None
+    dP = torch.empty(B * Nq * H, Lp, device="cuda", dtype=torch.bfloat16)
+    K.relpos_scatter(dQf, dP, inv, dims, scale)
+    dR_old = Fn.wgrad(dP, Qf.view(-1, DQK)[:, :D])
+    dq_old = K.gemm(dP, Rcat, b_km=True, resid=dQf.view(-1, DQK)[:, :D]).view(B, Nq, H, D)
+    # fp32 reference from the bf16-rounded scaled gradients (what both paths feed the matrix cores)
+    kh, kw, kt = k_thw[1], k_thw[2], k_thw[0]
+    Rh, Rw, Rt = (t.float() for t in tabs)
+    ih, iw, it = (i.cpu().long() for i in idx)
+    gaug = (dQf[..., D:].float().cpu() / scale).bfloat16().float()
+    gv = gaug[:, 1:].reshape(B, *q_thw, H, A)
+    qf = Qf[..., :D].float().cpu()[:, 1:].reshape(B, *q_thw, H, D)
+    dq_ref = dQf[..., :D].float().cpu().clone()
+    dqv = dq_ref[:, 1:].view(B, *q_thw, H, D)
+    dqv += torch.einsum("bthwnk,hkd->bthwnd", gv[..., :kh], Rh[ih])
+    dqv += torch.einsum("bthwnk,wkd->bthwnd", gv[..., kh:kh + kw], Rw[iw])
+    dqv += torch.einsum("bthwnk,tkd->bthwnd", gv[..., kh + kw:kh + kw + kt], Rt[it])
+    dRh = torch.zeros_like(Rh).index_put_((ih.reshape(-1),), torch.einsum("bthwnk,bthwnd->hkd", gv[..., :kh], qf).reshape(-1, D), accumulate=True)
+    dRw = torch.zeros_like(Rw).index_put_((iw.reshape(-1),), torch.einsum("bthwnk,bthwnd->wkd", gv[..., kh:kh + kw], qf).reshape(-1, D), accumulate=True)
+    dRt = torch.zeros_like(Rt).index_put_((it.reshape(-1),), torch.einsum("bthwnk,bthwnd->tkd", gv[..., kh + kw:kh + kw + kt], qf).reshape(-1, D), accumulate=True)
+    dR_ref = torch.cat([dRh, dRw, dRt], 0)
+    n = sum(lens)
+    rel = lambda a, b: (a - b).abs().max().item() / b.abs().max().item()
+    assert rel(dq.float().cpu(), dq_ref) < 1e-2
+    assert rel(dq_old.float().cpu(), dq_ref) < 1e-2
+    assert rel(dR[:n].cpu(), dR_ref) < 1e-3                       # exact bf16 products, fp32 accumulation
+    assert rel(dR_old[:n].float().cpu(), dR_ref) < 1e-3
+    assert torch.all(dR[n:] == 0)
+    dR2 = dR.clone()
+    K.relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dR2)        # accumulates
+    assert rel(dR2[:n].cpu(), 2 * dR_ref) < 1e-3
