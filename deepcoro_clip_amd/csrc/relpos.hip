@@ -364,7 +364,7 @@ __device__ unsigned long long g_rbprof[8];
 #define RBP(i, t0) do { } while (0)
 #endif
 template <int NMT>   // 32-row slabs of dR per wave: ceil(LPp / 32 / 4)
-__global__ __launch_bounds__(256) void relpos_bwd_mfma_kernel(const bf16_t* __restrict__ dQf, const bf16_t* __restrict__ Qf,
+__global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(const bf16_t* __restrict__ dQf, const bf16_t* __restrict__ Qf,
                                                               bf16_t* __restrict__ dq, const bf16_t* __restrict__ Rcat,
                                                               float* __restrict__ ws, const int* __restrict__ idx_h,
                                                               const int* __restrict__ idx_w, const int* __restrict__ idx_t,
@@ -405,39 +405,36 @@ __global__ __launch_bounds__(256) void relpos_bwd_mfma_kernel(const bf16_t* __re
   // The global loads of tile i+1 (q row, residual row, augmentation gradients: 8 x 16 bytes per thread) are issued at the START
   // of tile i, right after tile i's registers went to LDS, so a whole tile of work covers their latency (in-kernel timers: with
   // the loads issued mid-tile, and the residual fetched in the epilogue, three exposed memory waits were 90 % of a tile).
-  u32x4 pq[3], pz[3], pg[2];
-  RowPos pp_;
-  bool plive;
-  auto prefetch = [&](unsigned tile) {
+  struct Pre { u32x4 q[3], z[3], g[2]; RowPos p; bool live; };
+  Pre preA, preB;
+  auto prefetch = [&](Pre& pr, unsigned tile) {
     const unsigned row = tile * 64u + r;
-    plive = tile < ntiles && row < rows;
-    pp_ = row_pos(plive ? row : 0u, g, dv, Nq);
-    const int64_t off = pp_.b * g.sb + (int64_t)pp_.n * g.sn + pp_.hd * g.sh;
+    pr.live = tile < ntiles && row < rows;
+    pr.p = row_pos(pr.live ? row : 0u, g, dv, Nq);
+    const int64_t off = pr.p.b * g.sb + (int64_t)pr.p.n * g.sn + pr.p.hd * g.sh;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      pq[c] = plive ? reinterpret_cast<const u32x4*>(Qf + off)[part * 3 + c] : z4;
-      pz[c] = plive ? reinterpret_cast<const u32x4*>(dQf + off)[part * 3 + c] : z4;
+      pr.q[c] = pr.live ? reinterpret_cast<const u32x4*>(Qf + off)[part * 3 + c] : z4;
+      pr.z[c] = pr.live ? reinterpret_cast<const u32x4*>(dQf + off)[part * 3 + c] : z4;
     }
-    pg[0] = plive ? reinterpret_cast<const u32x4*>(dQf + off + g.D + part * apq)[0] : z4;
-    pg[1] = (plive && apq > 8) ? reinterpret_cast<const u32x4*>(dQf + off + g.D + part * apq)[1] : z4;
+    pr.g[0] = pr.live ? reinterpret_cast<const u32x4*>(dQf + off + g.D + part * apq)[0] : z4;
+    pr.g[1] = (pr.live && apq > 8) ? reinterpret_cast<const u32x4*>(dQf + off + g.D + part * apq)[1] : z4;
   };
-  prefetch(blockIdx.x);
-  RBP(0, tp0);
-  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  auto do_tile = [&](Pre& pr, unsigned tile) {
     const unsigned long long t1 = RBT();
     __syncthreads();   // the previous tile's fragment reads are done (and, first time, the tables are staged)
     RBP(1, t1);
     const unsigned long long t2 = RBT();
-    const RowPos p = pp_;
-    const bool live = plive;
-    const u32x4 gr[2] = {pg[0], pg[1]};
+    const RowPos p = pr.p;
+    const bool live = pr.live;
+    const u32x4 gr[2] = {pr.g[0], pr.g[1]};
     for (int i = tid; i < zunits; i += 256) reinterpret_cast<u32x4*>(dP)[i] = z4;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      reinterpret_cast<u32x4*>(Qs + r * 192)[part * 3 + c] = pq[c];
-      reinterpret_cast<u32x4*>(Rz + r * RZP)[part * 3 + c] = pz[c];
+      reinterpret_cast<u32x4*>(Qs + r * 192)[part * 3 + c] = pr.q[c];
+      reinterpret_cast<u32x4*>(Rz + r * RZP)[part * 3 + c] = pr.z[c];
     }
-    prefetch(tile + gridDim.x);
+    prefetch(pr, tile + (NMT == 2 ? 2 : 1) * gridDim.x);
     __syncthreads();   // zeros are in place
     RBP(2, t2);
     const unsigned long long t3 = RBT();
@@ -506,6 +503,18 @@ __global__ __launch_bounds__(256) void relpos_bwd_mfma_kernel(const bf16_t* __re
       }
     }
     RBP(5, t5);
+  };
+  // NMT == 2 (the 240-row tables of block 0: one block per CU anyway): two register sets, two tiles of loads in flight
+  // (349 -> 269 us).  NMT == 1: one set — the second costs 130 VGPRs and the second block per CU (stage 2: 57 -> 64 us).
+  constexpr int DIST = NMT == 2 ? 2 : 1;
+  prefetch(preA, blockIdx.x);
+  if constexpr (DIST == 2) prefetch(preB, blockIdx.x + gridDim.x);
+  RBP(0, tp0);
+  for (unsigned tile = blockIdx.x; tile < ntiles; tile += DIST * gridDim.x) {
+    do_tile(preA, tile);
+    if constexpr (DIST == 2) {
+      if (tile + gridDim.x < ntiles) do_tile(preB, tile + gridDim.x);   // block-uniform
+    }
   }
   const unsigned long long t6 = RBT();
   // ---- this block's table gradient -> workspace [block][g.L][96]

@@ -671,9 +671,9 @@ class MvitAttnCoreFn(torch.autograd.Function):
         dims_q = K.relpos_dims(B, H, D, A, Lp, geo["q"].out_thw, geo["k"].out_thw, lens)
         rows_q = B * Nq * H
         dq = None
-        # dP built and consumed in LDS (no [rows, L] tensor) where that is faster than scatter + two GEMMs (tools/relpos_bench.py:
-        # every 32-column augmentation, and the 64-column one from 300 k rows up)
-        if FUSED_RELPOS_BWD and dt == torch.bfloat16 and D == 96 and (A == 32 or rows_q >= 300000):
+        # dP built and consumed in LDS (no [rows, L] tensor): faster than scatter + two GEMMs at every block geometry
+        # (tools/relpos_bench.py: 584 -> 271 us in block 0, 71 -> 43 us in the stage-2 blocks)
+        if FUSED_RELPOS_BWD and dt == torch.bfloat16 and D == 96:
             drel_cat = zeros_f32((Lp, D), dev)
             dq = K.relpos_aug_bwd(dQf, Qf, Rcat, cfg["idx"], dims_q, scale, drel_cat)
         if dq is None:
