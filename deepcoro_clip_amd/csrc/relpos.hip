@@ -227,19 +227,16 @@ __global__ __launch_bounds__(256) void relpos_kaug_kernel(T* __restrict__ Kf, Re
 }
 
 // =====================================================================================================
-// Fused rel-pos forward (bf16): the inner products are taken ONLY against the k_h + k_w + k_t table rows a query needs,
-// straight from q, so P ([rows, L], L = 72 .. 240 against 22 used entries per row: 385 MB in block 0) is never written.
-// ~10x fewer MACs than the stacked-table GEMM, on the vector ALUs: a 16-lane group owns a query row; lane i computes the
-// complete dot products of augmentation columns 2i, 2i + 1 with v_dot2c_f32_bf16 on packed operands (q row in registers,
-// table rows from LDS).  Measured (tools/relpos_bench.py, 32 clips): block 0 155 us against 258 us for GEMM + gather,
-// stage-2 blocks 31 against 36; with 64 augmentation columns (the 14 x 14 key grids) the GEMM path is faster and stays.
-// A backward of the same shape (dq and the table gradient from the augmentation columns with LDS float atomics for the
-// axis whose table row changes along the walk) was built and measured 6-30x SLOWER than scatter + two GEMMs (ds_add_f32
-// retires about one lane per clock per CU), so the backward keeps the dP tensor.
+// Fused rel-pos kernels (bf16, head_dim 96): forward and backward work on tiles of 64 consecutive (clip, token, head) rows and keep
+// the tile's slice of P / dP ([rows, L], L = 48 .. 240 against 22 .. 36 used entries per row; 385 MB each way in block 0) in LDS,
+// so the tensor never exists in HBM; the products stay on the matrix cores with the arithmetic of the GEMM path.
+// History of this section (measured, tools/relpos_bench.py): a VALU forward (v_dot2c_f32_bf16 dot products against only the used
+// table rows) beat GEMM + gather for 32 augmentation columns but lost for 64 and was replaced by the MFMA tile kernel below,
+// which wins everywhere (stage 2: 34 -> 19 us, block 1: 77 -> 50); a VALU backward with LDS float atomics for the table gradient
+// was 6-30x slower than scatter + two GEMMs (ds_add_f32 retires about one lane per clock per CU).
 // Table rows of idx_a: idx_a[coord][j] (the reference's integer-truncated distance), staged in LDS.
 typedef __bf16 rbf2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ int rf_swz(int l) { return (l ^ (l >> 3)) & 15; }
 
 struct RowPos { int b, n, hd, t, hh, w; bool tok; };
 __device__ __forceinline__ RowPos row_pos(unsigned row, const RelGeom& g, const RelDiv& dv, int Nq) {
@@ -255,77 +252,6 @@ __device__ __forceinline__ RowPos row_pos(unsigned row, const RelGeom& g, const 
   p.hh = fdiv(r, dv.qw);
   p.w = r - p.hh * g.qw;
   return p;
-}
-
-// LDS: table rows at 256-byte pitch (12 chunks of 16 B in 16 slots, slot = chunk ^ swz(row): lanes of a group read
-// DIFFERENT rows at the same chunk), then the three index tables.
-template <int JPL>
-__global__ __launch_bounds__(256) void relpos_aug_fwd_kernel(bf16_t* __restrict__ Qf, const bf16_t* __restrict__ Rcat,
-                                                             const int* __restrict__ idx_h, const int* __restrict__ idx_w,
-                                                             const int* __restrict__ idx_t, RelGeom g, RelDiv dv,
-                                                             float inv_scale, unsigned rows) {
-  extern __shared__ __attribute__((aligned(16))) char rlds[];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < g.L * 12; i += 256) {
-    const int l = i / 12, c = i - l * 12;
-    *reinterpret_cast<u32x4*>(rlds + l * 256 + ((c ^ rf_swz(l)) << 4)) = reinterpret_cast<const u32x4*>(Rcat)[i];
-  }
-  int* ih = reinterpret_cast<int*>(rlds + g.L * 256);
-  int* iw = ih + g.qh * g.kh;
-  int* it = iw + g.qw * g.kw;
-  for (int i = tid; i < g.qh * g.kh; i += 256) ih[i] = idx_h[i];
-  for (int i = tid; i < g.qw * g.kw; i += 256) iw[i] = idx_w[i] + g.Lh;
-  for (int i = tid; i < g.qt * g.kt; i += 256) it[i] = idx_t[i] + g.Lh + g.Lw;
-  __syncthreads();
-  const int Nq = g.qt * g.qh * g.qw + g.has_cls;
-  const int li = tid & 15;
-  const int areal = g.kh + g.kw + g.kt;
-  const unsigned ngroups = gridDim.x * 16u;
-  for (unsigned row = (blockIdx.x * 256u + tid) >> 4; row < rows; row += ngroups) {
-    const RowPos p = row_pos(row, g, dv, Nq);
-    bf16_t* qrow = Qf + p.b * g.sb + (int64_t)p.n * g.sn + p.hd * g.sh;
-    float acc[JPL];
-    int laddr[JPL], lsw[JPL];
-#pragma unroll
-    for (int e = 0; e < JPL; ++e) {
-      const int j = JPL * li + e;
-      const bool ok = p.tok && j < areal;
-      const int ax = (j >= g.kh) + (j >= g.kh + g.kw);
-      const int* tp = ax == 0 ? ih + p.hh * g.kh + j : (ax == 1 ? iw + p.w * g.kw + (j - g.kh) : it + p.t * g.kt + (j - g.kh - g.kw));
-      const int l = ok ? *tp : 0;
-      laddr[e] = l * 256;
-      lsw[e] = rf_swz(l);
-      acc[e] = 0.0f;
-    }
-    if (p.tok) {  // uniform over the 16 lanes of the row
-      u32x4 q[12];
-#pragma unroll
-      for (int c = 0; c < 12; ++c) q[c] = reinterpret_cast<const u32x4*>(qrow)[c];
-#pragma unroll
-      for (int c = 0; c < 12; ++c) {
-#pragma unroll
-        for (int e = 0; e < JPL; ++e) {
-          const u32x4 rv = *reinterpret_cast<const u32x4*>(rlds + laddr[e] + ((c ^ lsw[e]) << 4));
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            const unsigned qa = q[c][d], ra = rv[d];  // rvalues: __builtin_bit_cast of a vector-element lvalue reads element 0
-            acc[e] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rbf2, qa), __builtin_bit_cast(rbf2, ra), acc[e], false);
-          }
-        }
-      }
-    }
-    unsigned out[JPL / 2];
-#pragma unroll
-    for (int e = 0; e < JPL; e += 2) {
-      const float v0 = (JPL * li + e < areal) ? acc[e] * inv_scale : 0.0f;
-      const float v1 = (JPL * li + e + 1 < areal) ? acc[e + 1] * inv_scale : 0.0f;
-      const rbf2 t = {(bf16_t)v0, (bf16_t)v1};
-      out[e / 2] = __builtin_bit_cast(unsigned, t);
-    }
-    unsigned* dst = reinterpret_cast<unsigned*>(qrow + g.D + JPL * li);
-#pragma unroll
-    for (int e = 0; e < JPL / 2; ++e) dst[e] = out[e];
-  }
 }
 
 // ------------------------------------------------------------------------------- fused backward on the matrix cores
@@ -533,6 +459,111 @@ __global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(
   RBP(6, t6);
 }
 
+// Forward on the matrix cores, same tiling: P = q Rcat^T for a 64-row tile lands in LDS (bf16, as the GEMM would write it), the
+// tile's threads pick each row's k_h + k_w + k_t entries, scale and store the augmentation columns.  Bit-identical to dcc_gemm +
+// dcc_relpos_gather (same roundings) without the [rows, L] tensor; serves every augmentation width.
+template <int NNT>   // 32-row slabs of the tables per wave: ceil(LPp / 32 / 4)
+__global__ __launch_bounds__(256, NNT == 1 ? 2 : 1) void relpos_fwd_mfma_kernel(bf16_t* __restrict__ Qf, const bf16_t* __restrict__ Rcat,
+                                                                                const int* __restrict__ idx_h, const int* __restrict__ idx_w,
+                                                                                const int* __restrict__ idx_t, RelGeom g, RelDiv dv,
+                                                                                float inv_scale, unsigned rows, int LPp, int ppitch,
+                                                                                unsigned ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char rlds[];
+  constexpr int QP = 208;                // q tile row pitch: 13 16-byte units (odd: the k-contiguous fragment reads spread over the banks)
+  char* Rs = rlds;                       // [LPp][QP]     stacked tables (k-contiguous B operand), zero rows past g.L
+  char* Qs = Rs + LPp * QP;              // [64][QP]
+  char* Ps = Qs + 64 * QP;               // [64][ppitch]  P tile, bf16
+  int* ih = reinterpret_cast<int*>(Ps + 64 * ppitch);
+  int* iw = ih + g.qh * g.kh;
+  int* it = iw + g.qw * g.kw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  const u32x4 z4 = {0u, 0u, 0u, 0u};
+  for (int i = tid; i < LPp * 12; i += 256) {
+    const int l = i / 12, c = i - l * 12;
+    *reinterpret_cast<u32x4*>(Rs + l * QP + c * 16) = l < g.L ? reinterpret_cast<const u32x4*>(Rcat)[i] : z4;
+  }
+  for (int i = tid; i < g.qh * g.kh; i += 256) ih[i] = idx_h[i];
+  for (int i = tid; i < g.qw * g.kw; i += 256) iw[i] = idx_w[i] + g.Lh;
+  for (int i = tid; i < g.qt * g.kt; i += 256) it[i] = idx_t[i] + g.Lh + g.Lw;
+  const int Nq = g.qt * g.qh * g.qw + g.has_cls;
+  const int areal = g.kh + g.kw + g.kt;
+  const int r = tid >> 2, part = tid & 3, apq = g.A >> 2;
+  u32x4 pq[3];
+  RowPos pp_;
+  bool plive;
+  auto prefetch = [&](unsigned tile) {
+    const unsigned row = tile * 64u + r;
+    plive = tile < ntiles && row < rows;
+    pp_ = row_pos(plive ? row : 0u, g, dv, Nq);
+    const int64_t off = pp_.b * g.sb + (int64_t)pp_.n * g.sn + pp_.hd * g.sh;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pq[c] = plive ? reinterpret_cast<const u32x4*>(Qf + off)[part * 3 + c] : z4;
+  };
+  prefetch(blockIdx.x);
+  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();   // the previous tile's P reads are done (and, first time, the tables are staged)
+    const RowPos p = pp_;
+    const bool live = plive;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(Qs + r * QP + (part * 3 + c) * 16) = pq[c];
+    prefetch(tile + gridDim.x);
+    __syncthreads();   // the q tile is complete
+    // P^T form: lanes = rows, a lane's registers = 4 consecutive table rows -> 8-byte LDS writes of bf16
+#pragma unroll
+    for (int i = 0; i < NNT; ++i) {
+      const int nt = wave + 4 * i;
+      if (32 * nt < LPp) {   // wave-uniform
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+          const bf16x8 fb = rfrag_kc(Rs, QP, 32 * nt, s, lane);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[m] = mma16(fb, rfrag_kc(Qs, QP, 32 * m, s, lane), acc[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          char* prow = Ps + (32 * m + (lane & 31)) * ppitch + (32 * nt + 4 * h) * 2;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)acc[m][4 * g4 + e];
+            *reinterpret_cast<bf16x4*>(prow + 16 * g4) = o;
+          }
+        }
+      }
+    }
+    __syncthreads();   // the P tile is complete
+    if (live) {        // thread (row, quarter): augmentation columns quarter * A/4 .. of its row
+      unsigned out[8];
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        if (e >= apq) break;
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = part * apq + e + u;
+          v[u] = 0.0f;
+          if (p.tok && j < areal) {
+            const int ax = (j >= g.kh) + (j >= g.kh + g.kw);
+            const int l = ax == 0 ? ih[p.hh * g.kh + j] : (ax == 1 ? iw[p.w * g.kw + (j - g.kh)] : it[p.t * g.kt + (j - g.kh - g.kw)]);
+            v[u] = (float)*reinterpret_cast<const bf16_t*>(Ps + r * ppitch + l * 2) * inv_scale;
+          }
+        }
+        const rbf2 t = {(bf16_t)v[0], (bf16_t)v[1]};
+        out[e >> 1] = __builtin_bit_cast(unsigned, t);
+      }
+      u32x4* dst = reinterpret_cast<u32x4*>(Qf + p.b * g.sb + (int64_t)p.n * g.sn + p.hd * g.sh + g.D + part * apq);
+      dst[0] = u32x4{out[0], out[1], out[2], out[3]};
+      if (apq > 8) dst[1] = u32x4{out[4], out[5], out[6], out[7]};
+    }
+  }
+}
+
 // out[i] += sum_b ws[b][i]  (i over n4 float4 columns): block = 64 columns x 4 row lanes, gridDim.y row slices, the four lanes
 // fold through LDS and every slice adds its sum with one atomic per element.
 __global__ __launch_bounds__(256) void relpos_fold_kernel(const float* __restrict__ ws, float* __restrict__ out, int nb, int n4) {
@@ -634,34 +665,6 @@ extern "C" int dcc_relpos_kaug(void* Kf, const int* dims, const int64_t* strides
   return dcc_check_launch();
 }
 
-// Fused forward: Qf[row][D + j] = <q_row, R_a[idx_a[coord_a(row)][j_a]]> / scale for the k_h + k_w + k_t used columns, zeros in
-// the padding columns and the class-token rows.  Rcat: the three tables stacked [L][D] (h, w, t), bf16, D == 96, A == 32.
-extern "C" int dcc_relpos_aug_fwd(void* Qf, const void* Rcat, const int* idx_h, const int* idx_w, const int* idx_t,
-                                  const int* dims, const int64_t* strides, float scale, int dtype, void* stream) {
-  if (!Qf || !Rcat || !idx_h || !idx_w || !idx_t || !dims || !strides) return DCC_ERR_ARG;
-  if (dtype != DCC_BF16) return DCC_ERR_UNSUPPORTED;
-  RelGeom g = mk(dims, strides);
-  if (g.D != 96 || g.A != 32 || g.A < g.kh + g.kw + g.kt || g.L < g.Lh + g.Lw + g.Lt) return DCC_ERR_UNSUPPORTED;
-  if ((g.sb % 8) || (g.sn % 8) || (g.sh % 8) || (((uintptr_t)Qf) & 15) || (((uintptr_t)Rcat) & 15)) return DCC_ERR_UNSUPPORTED;
-  const int64_t rows = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H;
-  const size_t lds = (size_t)g.L * 256 + (size_t)(g.qh * g.kh + g.qw * g.kw + g.qt * g.kt) * 4;
-  if (rows >= (1LL << 31) || lds > 96 * 1024) return DCC_ERR_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
-  const RelDiv dv{mkdiv(g.H), mkdiv(g.qt * g.qh * g.qw + g.has_cls), mkdiv(g.qw * g.qh), mkdiv(g.qw), mkdiv(1), mkdiv(1)};
-  int64_t nb = (rows + 15) / 16;
-  const int cap = 256 * (lds > 76 * 1024 ? 1 : (lds > 48 * 1024 ? 2 : 3)) * 2;   // persistent: the table staging is amortised over many rows
-  if (nb > cap) nb = cap;
-  auto k2 = relpos_aug_fwd_kernel<2>;
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-      return DCC_ERR_LAUNCH;
-    configured = true;
-  }
-  hipLaunchKernelGGL(k2, dim3((unsigned)nb), dim3(256), lds, st, (bf16_t*)Qf, (const bf16_t*)Rcat, idx_h, idx_w, idx_t, g, dv, 1.0f / scale, (unsigned)rows);
-  return dcc_check_launch();
-}
-
 // Fused backward: dq [B*Nq*H][D] = dQf[:, :D] + (dQf[:, D:] / scale) against the table rows; dRcat [L][D] fp32 is ACCUMULATED
 // into (the gradient of the three stacked tables); ws: scratch of max_blocks * L * D floats for the per-block partials (no
 // initialisation needed).  = dcc_relpos_scatter + dcc_gemm (dP Rcat + residual) + dcc_gemm (dP^T q).
@@ -715,3 +718,38 @@ extern "C" int dcc_relpos_prof_read(unsigned long long* out8, int reset) {
   return DCC_OK;
 }
 #endif
+
+// Forward on the matrix cores (bf16, D == 96, A in {32, 64}, L <= 256): Qf[row][D + j] exactly as dcc_gemm + dcc_relpos_gather
+// produce it, without the [rows, L] tensor.
+extern "C" int dcc_relpos_aug_fwd_mfma(void* Qf, const void* Rcat, const int* idx_h, const int* idx_w, const int* idx_t,
+                                       const int* dims, const int64_t* strides, float scale, int dtype, void* stream) {
+  if (!Qf || !Rcat || !idx_h || !idx_w || !idx_t || !dims || !strides) return DCC_ERR_ARG;
+  if (dtype != DCC_BF16) return DCC_ERR_UNSUPPORTED;
+  RelGeom g = mk(dims, strides);
+  if (g.D != 96 || (g.A != 32 && g.A != 64) || g.A < g.kh + g.kw + g.kt || g.L < g.Lh + g.Lw + g.Lt || (g.L % 8)) return DCC_ERR_UNSUPPORTED;
+  if ((g.sb % 8) || (g.sn % 8) || (g.sh % 8) || (((uintptr_t)Qf) & 15) || (((uintptr_t)Rcat) & 15)) return DCC_ERR_UNSUPPORTED;
+  const int64_t rows = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H;
+  const int LPp = (g.L + 31) & ~31;
+  if (LPp > 256 || rows >= (1LL << 31)) return DCC_ERR_UNSUPPORTED;
+  const int ppitch = LPp * 2 + 16;
+  const size_t lds = (size_t)LPp * 208 + 64 * 208 + (size_t)64 * ppitch + (size_t)(g.qh * g.kh + g.qw * g.kw + g.qt * g.kt) * 4;
+  if (lds > 150 * 1024) return DCC_ERR_UNSUPPORTED;
+  const int64_t ntiles = (rows + 63) / 64;
+  const int per_cu = (int)((160 * 1024) / lds);
+  int64_t nb = 256LL * (per_cu > 2 ? 2 : per_cu);
+  if (nb > ntiles) nb = ntiles;
+  hipStream_t st = (hipStream_t)stream;
+  const RelDiv dv{mkdiv(g.H), mkdiv(g.qt * g.qh * g.qw + g.has_cls), mkdiv(g.qw * g.qh), mkdiv(g.qw), mkdiv(1), mkdiv(1)};
+  auto k1 = relpos_fwd_mfma_kernel<1>;
+  auto k2 = relpos_fwd_mfma_kernel<2>;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+      return DCC_ERR_LAUNCH;
+    configured = true;
+  }
+  if (LPp <= 128) hipLaunchKernelGGL(k1, dim3((unsigned)nb), dim3(256), lds, st, (bf16_t*)Qf, (const bf16_t*)Rcat, idx_h, idx_w, idx_t, g, dv, 1.0f / scale, (unsigned)rows, LPp, ppitch, (unsigned)ntiles);
+  else hipLaunchKernelGGL(k2, dim3((unsigned)nb), dim3(256), lds, st, (bf16_t*)Qf, (const bf16_t*)Rcat, idx_h, idx_w, idx_t, g, dv, 1.0f / scale, (unsigned)rows, LPp, ppitch, (unsigned)ntiles);
+  return dcc_check_launch();
+}

@@ -541,8 +541,8 @@ class _Branches:
 # conv pool + LayerNorm of the q/k/v branches in one launch where dcc_pool_ln_fwd applies (bf16, head_dim 96);
 # DCC_FUSED_POOL_LN=0 keeps the two-kernel path for A/B runs
 FUSED_POOL_LN = os.environ.get("DCC_FUSED_POOL_LN", "1") != "0"
-# forward rel-pos inner products without the [rows, L] P tensor where that is faster (dcc_relpos_aug_fwd: bf16, 7 x 7 key
-# grids); DCC_FUSED_RELPOS=0 keeps the stacked-table GEMM + gather everywhere
+# forward rel-pos inner products per 64-row tile on the matrix cores, P never in HBM (dcc_relpos_aug_fwd_mfma, bf16);
+# DCC_FUSED_RELPOS=0 keeps the stacked-table GEMM + gather
 FUSED_RELPOS = os.environ.get("DCC_FUSED_RELPOS", "1") != "0"
 # rel-pos backward as one MFMA kernel that builds dP per 64-row tile in LDS (dcc_relpos_aug_bwd) instead of scatter + two GEMMs
 FUSED_RELPOS_BWD = os.environ.get("DCC_FUSED_RELPOS_BWD", "1") != "0"
@@ -601,9 +601,9 @@ class MvitAttnCoreFn(torch.autograd.Function):
         Lp = 8 * ((sum(lens) + 7) // 8)
         Rcat = stacked_tables((rel_h, rel_w, rel_t), Lp, D, dt)
         dims_q = K.relpos_dims(B, H, D, A, Lp, q_thw, k_thw, lens)
-        fused_rel = FUSED_RELPOS and K.relpos_fused_supported(Qf, D, A, k_thw, q_thw, Lp)
-        if fused_rel:  # products only against the table rows each query uses, straight from q: no P tensor
-            fused_rel = K.relpos_aug_fwd(Qf, Rcat, idx, dims_q, scale)
+        fused_rel = FUSED_RELPOS and dt == torch.bfloat16 and D == 96
+        if fused_rel:  # P of a 64-row tile lives in LDS only; same roundings as GEMM + gather
+            fused_rel = K.relpos_aug_fwd_mfma(Qf, Rcat, idx, dims_q, scale)
         if not fused_rel:
             q2d = Qf.view(-1, DQK)[:, :D]
             P = K.gemm(q2d, Rcat)

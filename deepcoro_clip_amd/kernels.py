@@ -427,21 +427,11 @@ def relpos_scatter(dQf, dP, inv, dims, scale):
            _i64(_strides3(dQf)), float(scale), L.dt(dQf), L.stream())
 
 
-def relpos_fused_supported(Qf: torch.Tensor, D: int, A: int, k_thw, q_thw=None, table_rows: int = 0) -> bool:
-    """Domain of dcc_relpos_aug_fwd (bf16, head_dim 96, 32 augmentation columns: the 7 x 7 key grids; with the 64 columns
-    of the 14 x 14 key grids the stacked-table GEMM + gather is faster, tools/relpos_bench.py)."""
-    lds = 0  # the kernel stages the stacked tables (256 B per row) and the three index tables in LDS
-    if q_thw is not None:
-        lds = table_rows * 256 + 4 * sum(q * k for q, k in zip(q_thw, k_thw))
-    return Qf.dtype == torch.bfloat16 and D == 96 and A == 32 and sum(k_thw) <= 32 and lds <= 96 * 1024
-
-
-def relpos_aug_fwd(Qf, Rcat, idx, dims, scale):
-    """Qf[..., D:] = rel-pos inner products of Qf[..., :D] against the table rows each query uses (no P tensor).
-    False when the shape is outside the kernel's domain (the caller then runs the GEMM + gather)."""
+def relpos_aug_fwd_mfma(Qf, Rcat, idx, dims, scale) -> bool:
+    """Qf[..., D:] from Qf[..., :D] on the matrix cores, tile-local P in LDS (any augmentation width); False when unsupported."""
     L.require_cuda(Qf, Rcat)
     assert Rcat.is_contiguous() and Rcat.dtype == Qf.dtype
-    return L.try_call("dcc_relpos_aug_fwd", L.ptr(Qf), L.ptr(Rcat), L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims,
+    return L.try_call("dcc_relpos_aug_fwd_mfma", L.ptr(Qf), L.ptr(Rcat), L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims,
                       _i64(_strides3(Qf)), float(scale), L.dt(Qf), L.stream())
 
 

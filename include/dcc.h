@@ -108,12 +108,10 @@ int dcc_relpos_gather(void* Qf, const void* P, const int* idx_h, const int* idx_
 int dcc_relpos_scatter(const void* dQf, void* dP, const int* inv_h, const int* inv_w, const int* inv_t,
                        const int* dims, const int64_t* strides, float scale, int dtype, void* stream);
 int dcc_relpos_kaug(void* Kf, const int* dims, const int64_t* strides, int dtype, void* stream);
-/* Fused forward (bf16, D == 96, A == 32): the products are taken only against the k_h + k_w + k_t table rows a query uses,
- * straight from the q columns of Qf, so P is never materialised.  Rcat = the three tables stacked [L][D] (h | w | t).
- * Qf[row][D + j] = <q_row, Rcat[base_a + idx_a[coord_a][j_a]]> / scale (zeros in the padding columns and class-token rows)
- * = dcc_gemm(q, Rcat) + dcc_relpos_gather.  DCC_ERR_UNSUPPORTED outside that domain. */
-int dcc_relpos_aug_fwd(void* Qf, const void* Rcat, const int* idx_h, const int* idx_w, const int* idx_t, const int* dims,
-                       const int64_t* strides, float scale, int dtype, void* stream);
+/* Forward on the matrix cores (bf16, D == 96, A in {32, 64}, L <= 256): per 64-row tile P = q Rcat^T lands in LDS and the
+ * augmentation columns are picked there; bit-identical to dcc_gemm + dcc_relpos_gather. */
+int dcc_relpos_aug_fwd_mfma(void* Qf, const void* Rcat, const int* idx_h, const int* idx_w, const int* idx_t, const int* dims,
+                            const int64_t* strides, float scale, int dtype, void* stream);
 /* Fused backward on the matrix cores (bf16, D == 96, A in {32, 64}, L <= 256): per 64-row tile the dP the scatter kernel would
  * write is built in LDS and consumed there: dq [B*N*H][D] = dP Rcat + dQf[:, :D], dRcat [L][D] fp32 += dP^T q — i.e.
  * dcc_relpos_scatter + the two dcc_gemm calls without the [rows, L] tensor.  ws: fp32 scratch [max_blocks * L * D] (per-block

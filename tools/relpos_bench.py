@@ -55,11 +55,13 @@ def main():
             Fn.wgrad(dP, Qf.view(-1, DQK)[:, :D])
             K.gemm(dP, Rcat, b_km=True, resid=dQf.view(-1, DQK)[:, :D])
 
-        fused = f"{t(lambda: K.relpos_aug_fwd(Qf, Rcat, idx, dims, scale)):7.1f} us" if K.relpos_fused_supported(Qf, D, A, k_thw) else "   n/a"
+        fused = ""
+        mf = f"{t(lambda: K.relpos_aug_fwd_mfma(Qf, Rcat, idx, dims, scale)):7.1f} us" if K.relpos_aug_fwd_mfma(Qf, Rcat, idx, dims, scale) else "   n/a"
+        fused = f"MFMA tile kernel {mf}"
         dR = torch.zeros(Lp, D, device="cuda")
         fb = K.relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dR)
         fusedb = f"{t(lambda: K.relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dR)):7.1f} us" if fb is not None else "   n/a"
-        print(f"{name}: rows {rows}, L {Lp}, A {A}:  fwd gemm+gather {t(old_f):7.1f} us, fused {fused};"
+        print(f"{name}: rows {rows}, L {Lp}, A {A}:  fwd gemm+gather {t(old_f):7.1f} us, {fused};"
               f"  bwd scatter+2 gemm {t(old_b):7.1f} us, fused (MFMA) {fusedb}", flush=True)
 
 
