@@ -94,7 +94,7 @@ def _oracle_trainer(vo, to, log_temp0):
     return lt, torch.optim.AdamW(groups, lr=1e-4)
 
 
-@pytest.mark.parametrize("dtype,steps,tol", [(torch.float32, 8, 1e-4), (torch.bfloat16, 20, 1e-2)])
+@pytest.mark.parametrize("dtype,steps,tol", [(torch.float32, 8, 1e-4), (torch.bfloat16, 12, 1e-2)])
 def test_train_step_loss_curve_vs_oracle(dtype, steps, tol):
     """Same weights, same batches, same optimizer on both sides: loss per step within north_star's tolerance
     (1e-4 fp32 / 1e-2 bf16), metric keys of the reference, embeddings' argmax identical at step 0."""
