@@ -190,6 +190,30 @@ def _join_wgrad():
         torch.cuda.current_stream().wait_stream(_WG["stream"])
 
 
+def side_param_work(fn, *tensors) -> bool:
+    """Run `fn` (kernels that only produce PARAMETER gradients: nothing on the data path waits for them) on the weight-gradient
+    side stream; the main stream re-joins it in the end-of-backward engine callback.  `tensors`: everything `fn` reads or writes
+    (kept alive for the side stream).  False (nothing launched) outside a backward pass."""
+    if not _WG["queued"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_wgrad)
+            _WG["queued"] = True
+        except RuntimeError:
+            return False
+    dev = tensors[0].device
+    if _WG["stream"] is None or _WG["stream"].device != dev:
+        _WG["stream"] = torch.cuda.Stream(device=dev)
+        _WG["event"] = torch.cuda.Event()
+    ws, ev = _WG["stream"], _WG["event"]
+    ev.record()            # the inputs are complete on the current stream here
+    ws.wait_event(ev)
+    with torch.cuda.stream(ws):
+        fn()
+    for t in tensors:
+        t.record_stream(ws)
+    return True
+
+
 def grads_unset(*params) -> bool:
     """True when none of the given tensors carries a .grad yet (then autograd adopts a fresh gradient buffer as is)."""
     return all(p is None or (p.is_leaf and p.grad is None) for p in params)  # non-leaf: not ours to reason about
@@ -550,6 +574,9 @@ FUSED_POOL_LN = os.environ.get("DCC_FUSED_POOL_LN", "1") != "0"
 FUSED_RELPOS = os.environ.get("DCC_FUSED_RELPOS", "1") != "0"
 # rel-pos backward as one MFMA kernel that builds dP per 64-row tile in LDS (dcc_relpos_aug_bwd) instead of scatter + two GEMMs
 FUSED_RELPOS_BWD = os.environ.get("DCC_FUSED_RELPOS_BWD", "1") != "0"
+# depthwise-conv weight gradients of the q/k/v pools on the parameter-gradient side stream (joined at the end of backward)
+POOL_WGRAD_SIDE = os.environ.get("DCC_POOL_WGRAD_SIDE", "1") != "0"
+PARAM_SIDE_OK = False   # set by the runner around backward: one rank, no accumulation, no gradient hooks that would read early
 
 
 class MvitAttnCoreFn(torch.autograd.Function):
@@ -619,6 +646,7 @@ class MvitAttnCoreFn(torch.autograd.Function):
         ctx.save_for_backward(qkv, conv["q"], conv["k"], conv["v"], mq, rq, mk, rk, mv, rv, Qf, Kf, Vn, O, lse,
                               wq.detach(), wk.detach(), wv.detach(), gq.detach(), gk.detach(), gv.detach(), Rcat)
         ctx.cfg, ctx.geo, ctx.A, ctx.residual, ctx.lens, ctx.Lp = cfg, geo, A, residual, lens, Lp
+        ctx.pool_params = (wq, wk, wv)
         return O.view(B * Nq, H * D)
 
     @staticmethod
@@ -641,6 +669,7 @@ class MvitAttnCoreFn(torch.autograd.Function):
         small = zeros_f32((3, 2, D), dev)  # LayerNorm gamma/beta gradients of the q, k, v pools
         small_w = zeros_f32((3, D, 27), dev)
         qkv5 = qkv.view(B, N, 3, H, D)
+        ctx.pool_w_unset = [grads_unset(p_) for p_ in ctx.pool_params]
 
         def pool_branch(name, i, dy4, conv, mean, rstd, gam, w):
             """LayerNorm backward -> pool data gradient + pool weight gradient of one of the q / k / v branches."""
@@ -655,7 +684,11 @@ class MvitAttnCoreFn(torch.autograd.Function):
             dconv = K.layernorm_bwd(dy2, conv.view(rows, D), mean, rstd, gam, dgam, dbet)
             dconv4 = dconv.view(B, g.n_out, H, D)
             K.pool_bwd_data(dconv4, dqkv[:, :, i], g, w.reshape(D, 27))
-            K.dwconv_bwd_weight(dconv4, qkv5[:, :, i], g, dw)
+            # the conv weight gradient feeds nothing but the optimizer: off the data path when autograd will adopt the buffer
+            # as is (no accumulate kernel on another stream), else in line
+            if not (POOL_WGRAD_SIDE and PARAM_SIDE_OK and ctx.pool_w_unset[i]
+                    and side_param_work(lambda: K.dwconv_bwd_weight(dconv4, qkv5[:, :, i], g, dw), dconv, qkv, small_w)):
+                K.dwconv_bwd_weight(dconv4, qkv5[:, :, i], g, dw)
             grads[name] = (dw.view(D, 1, 3, 3, 3), dgam, dbet)
 
         # the k and v branches only need dKf / dVn: they start on their own streams right away, underneath the

@@ -385,6 +385,8 @@ class VideoContrastiveLearningRunner:
             self._accum_grad = torch.full((), 1.0 / accum, device=clip_loss.device, dtype=clip_loss.dtype)
         # weight-gradient GEMMs off the critical chain (functional.wgrad): safe when every gradient buffer is adopted as is
         Fn.WGRAD_SIDE = self._wgrad_side and accum == 1 and self.world_size == 1 and not self._ddp_wrappers()
+        # parameter-only gradient kernels (the pools' conv weight gradients) may leave the data path under the same conditions
+        Fn.PARAM_SIDE_OK = accum == 1 and self.world_size == 1 and not self._ddp_wrappers()
         if accum > 1:  # torch DDP's no_sync(): only the window's last backward reduces the gradient buckets
             for w in self._ddp_wrappers():
                 w.begin_backward(sync=(self.step + 1) % accum == 0)
@@ -396,6 +398,7 @@ class VideoContrastiveLearningRunner:
                 total_loss.backward(self._accum_grad)  # == (loss / accum).backward() without an extra kernel
         finally:
             Fn.WGRAD_SIDE = False
+            Fn.PARAM_SIDE_OK = False
         return total_loss, video_emb, text_emb, diag
 
     def _forward_backward_cached(self, videos, input_ids, attention_mask, positive_mask, positive_weights, text_metadata,
