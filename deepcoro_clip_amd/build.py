@@ -18,7 +18,7 @@ LIB_PATH = PKG_DIR / "libdcc_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CFLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wno-unused-result", "-ffp-contract=fast",
-          *os.environ.get("DCC_CFLAGS", "").split()]  # e.g. DCC_CFLAGS=-DDCC_RING_PROFILE for scratch/ring_prof.py
+          *os.environ.get("DCC_CFLAGS", "").split()]  # e.g. DCC_CFLAGS=-DDCC_RING_PROFILE (crew timestamps of the ring GEMM)
 
 
 def _sources() -> list[Path]:

@@ -1661,7 +1661,7 @@ int launch_dw3_run(const void* x, void* y, const float* w, const PoolGeom& g, hi
   // runs of 7 output columns when the grid allows (56/28/14/7) and still leaves >= 2 waves per SIMD, else runs of 4
   const int64_t threads7 = (int64_t)g.B * g.H * g.To * g.Ho * ((g.Wo + 6) / 7) * cpr;
   bool w7 = (g.Wo % 7 == 0) && threads7 >= 131072;
-  if (const char* e = getenv("DCC_POOL_WT")) w7 = w7 && atoi(e) == 7;  // A/B knob for scratch/pool_bench.py
+  if (const char* e = getenv("DCC_POOL_WT")) w7 = w7 && atoi(e) == 7;  // A/B knob for tools/pool_bench.py
   RunGeom r = make_run_geom(g, vec, w7 ? 7 : 4);
   if (!set_spans(r, sizeof(TD), sizeof(T))) return DCC_ERR_UNSUPPORTED;  // caller falls back to the generic kernel
   const int items = r.runs + (g.has_cls ? g.B * g.H : 0);
@@ -1694,7 +1694,7 @@ extern "C" int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* arg
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) {
-    // measured (scratch/pool_bench3.py): with buffer-addressed loads the run kernel wins for every stride of the model
+    // measured (round 1, tools/pool_bench.py today): with buffer-addressed loads the run kernel wins for every stride of the model
     const int S = dw3_stride(g, vec);
     int rr = DCC_ERR_UNSUPPORTED;
     static const int smax = getenv("DCC_POOL_RUN_SMAX") ? atoi(getenv("DCC_POOL_RUN_SMAX")) : 8;

@@ -602,7 +602,7 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   const int variant = (flags >> 8) & 0xff;  // tuning knob (bench / tests only): 1 = BK 32 for the 128-tile bf16 kernels, 2 = 64x64 tiles, 3 = no ring kernel
   const bool small = in_dtype == DCC_BF16 && (t128 < 192 || variant == 2);
   const int bmn = small ? 64 : 128;
-  // persistent LDS-DMA ring kernel: the towers' large GEMMs, and (measured, scratch/gemm_small.py) also the small grids
+  // persistent LDS-DMA ring kernel: the towers' large GEMMs, and (measured in round 1) also the small grids
   // of the text tower and the deep-K rel-pos table gradients, where its 3-4 stage pipeline hides the per-step load
   // latency the tiled kernel exposes (variant 6 restores the tiled kernel for small grids)
   if (in_dtype == DCC_BF16 && aligned && (variant == 8 || variant == 9 || variant == 11)) {  // A/B knob: force the wide-tile kernel

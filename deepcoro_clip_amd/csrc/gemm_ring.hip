@@ -752,7 +752,7 @@ int launch(const GemmParams& p, const Geo& geo, hipStream_t st) {
 }  // namespace
 
 #ifdef DCC_RING_PROFILE
-extern "C" int dcc_gemm_ring_profile(unsigned long long* out, int reset) {  // debug builds only (scratch/)
+extern "C" int dcc_gemm_ring_profile(unsigned long long* out, int reset) {  // debug builds only (-DDCC_RING_PROFILE)
   if (reset) { unsigned long long z[8] = {0}; return hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) == hipSuccess ? 0 : -1; }
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }

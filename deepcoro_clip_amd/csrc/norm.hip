@@ -345,7 +345,7 @@ int ln_bwd_t(const void* dy, int64_t lddy, const void* x, int64_t ldx, const flo
   if (pick(C / Vec16<T>::N, lpr, iters)) return DCC_ERR_UNSUPPORTED;
   const TD* dyp = (const TD*)dy; const T* xp = (const T*)x; TD* dxp = (TD*)dx; const TD* drp = (const TD*)dres;
   static const unsigned lnb_cap = getenv("DCC_LNB_CAP") ? (unsigned)atoi(getenv("DCC_LNB_CAP")) : 512u;
-  // measured (scratch/ln_bench.py): 512 blocks up to ~30 M elements, 1024 beyond (block 0/1 per-head norms)
+  // measured (round 1): 512 blocks up to ~30 M elements, 1024 beyond (block 0/1 per-head norms)
   static const unsigned lnb_cap_env = getenv("DCC_LNB_CAP_WS") ? (unsigned)atoi(getenv("DCC_LNB_CAP_WS")) : 0u;
   const unsigned lnb_cap_ws = lnb_cap_env ? lnb_cap_env : (rows * C >= (32 << 20) ? 1024u : 512u);
   const unsigned ws_fit = (1u << 20) / (unsigned)(2 * C);  // block partials the workspace holds (DCC_LN_WS_FLOATS in include/dcc.h)

@@ -169,7 +169,7 @@ def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=N
 def wgrad_splitk(rows: int, n: int, k: int) -> int:
     """Split factor for weight-gradient GEMMs (reduction over `rows`, output n x k).
 
-    Measured on MI355X (scratch/wgrad_sweep*.py) with the persistent ring kernel: one work item (128x128 output tile x
+    Measured on MI355X (round 1 sweeps; tools/gemm_bench.py today) with the persistent ring kernel: one work item (128x128 output tile x
     K split) per CU is the sweet spot — fewer leave CUs idle, more only add fp32 atomics (served at the memory side).
     So: the largest split with tiles x split <= 256 CUs; outputs with more tiles than half the CUs pick the split
     (<= 4) that wastes least of the last round of items."""
