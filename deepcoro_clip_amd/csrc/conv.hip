@@ -769,11 +769,28 @@ __device__ __forceinline__ void ln96_row_store(const float* v, const float* gam,
   if (lane0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+// One-hot key augmentation of the rel-pos contraction (relpos.hip: e(k) = [1{k_h} | 1{k_w} | 1{k_t}] behind the key, zeros for
+// the class token) written by the k pool itself: columns D .. D + aug of the row at `orow`, aug / 16 columns per lane.
+__device__ __forceinline__ void kaug_row_store(bf16_t* orow_l0, int l, int aug, int ch, int cw, int ct) {
+  const int per = aug >> 4;   // 2 (aug 32) or 4 (aug 64) columns per lane
+  unsigned v[2] = {0u, 0u};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (e < per) {
+      const int col = l * per + e;
+      if (col == ch || col == cw || col == ct) v[e >> 1] |= 0x3f80u << (16 * (e & 1));   // bf16 1.0
+    }
+  }
+  unsigned* dst = reinterpret_cast<unsigned*>(orow_l0 + 96 + l * per);
+  dst[0] = v[0];
+  if (per > 2) dst[1] = v[1];
+}
+
 template <int S, int WT, int PD>
 __global__ __launch_bounds__(256, PD == 0 ? 4 : 2) void dw3_ln_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, bf16_t* __restrict__ o,
                                                      int64_t ldo, const float* __restrict__ w, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, float eps, RunGeom r) {
+                                                     float* __restrict__ rstd, float eps, RunGeom r, int aug) {
   constexpr int NC = (WT - 1) * S + 3;
   __shared__ f32x4 wA[27 * 16];   // channels 6l .. 6l+3 of tap k at [k * 16 + l]
   __shared__ f32x2 wB[27 * 16];   // channels 6l+4, 6l+5
@@ -816,6 +833,7 @@ __global__ __launch_bounds__(256, PD == 0 ? 4 : 2) void dw3_ln_kernel(const bf16
       for (int e = 0; e < 6; ++e) { gam[e] = gbs[l * 6 + e]; bet[e] = gbs[96 + l * 6 + e]; }
       const int64_t row = ((int64_t)b * No) * g.H + hd;
       ln96_row_store(v, gam, bet, eps, o + row * ldo + l * 6, mean, rstd, row, l == 0);
+      if (aug) kaug_row_store(o + row * ldo, l, aug, -1, -1, -1);   // class token: zeros
     }
     return;
   }
@@ -909,6 +927,7 @@ __global__ __launch_bounds__(256, PD == 0 ? 4 : 2) void dw3_ln_kernel(const bf16
       float v[6];
       raw6_to_f32(q, v);
       ln96_row_store(v, gam, bet, eps, orow, mean, rstd, row, l == 0);
+      if (aug) kaug_row_store(orow - l * 6, l, aug, p.ho, g.Ho + p.w0 + i, g.Ho + g.Wo + p.to);
     }
     yrow += g.syn; orow += ostep; row += g.H;
   }
@@ -1732,12 +1751,14 @@ extern "C" int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* arg
 // stride ldo, mean / rstd fp32 per row.  DCC_ERR_UNSUPPORTED outside that domain (callers use dcc_pool_fwd + dcc_layernorm_fwd).
 extern "C" int dcc_pool_ln_fwd(const void* x, void* y, void* o, int64_t ldo, const float* w, const float* gamma,
                                const float* beta, float* mean, float* rstd, const int* dims, const int64_t* strides, float eps,
-                               int dtype, void* stream) {
+                               int aug, int dtype, void* stream) {
   if (!x || !y || !o || !w || !gamma || !beta || !mean || !rstd || !dims || !strides) return DCC_ERR_ARG;
   if (dtype != DCC_BF16) return DCC_ERR_UNSUPPORTED;
   PoolGeom g = make_geom(dims, strides);
   if (g.B <= 0 || g.H <= 0 || g.T <= 0 || g.Hs <= 0 || g.Ws <= 0) return DCC_ERR_ARG;
   if (g.C != 96) return DCC_ERR_UNSUPPORTED;
+  if (aug != 0 && aug != 32 && aug != 64) return DCC_ERR_ARG;
+  if (aug && (ldo < 96 + aug || g.To + g.Ho + g.Wo > aug || (ldo % 2))) return DCC_ERR_UNSUPPORTED;
   const int S = dw3_stride(g, 2);
   if (S == 0) return DCC_ERR_UNSUPPORTED;
   const int64_t st[] = {g.sxb, g.sxn, g.sxh, g.syb, g.syn, g.syh, ldo};
@@ -1753,8 +1774,8 @@ extern "C" int dcc_pool_ln_fwd(const void* x, void* y, void* o, int64_t ldo, con
   static const int pd = getenv("DCC_POOL_LN_PD") ? atoi(getenv("DCC_POOL_LN_PD")) : 1;  // A/B knob of tools/pool_bench.py
 #define POOL_LN(S_, WT_)                                                                                                        \
   do {                                                                                                                          \
-    if (pd == 0) hipLaunchKernelGGL((dw3_ln_kernel<S_, WT_, 0>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)o, ldo, w, gamma, beta, mean, rstd, eps, r); \
-    else hipLaunchKernelGGL((dw3_ln_kernel<S_, WT_, 1>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)o, ldo, w, gamma, beta, mean, rstd, eps, r); \
+    if (pd == 0) hipLaunchKernelGGL((dw3_ln_kernel<S_, WT_, 0>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)o, ldo, w, gamma, beta, mean, rstd, eps, r, aug); \
+    else hipLaunchKernelGGL((dw3_ln_kernel<S_, WT_, 1>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)o, ldo, w, gamma, beta, mean, rstd, eps, r, aug); \
   } while (0)
   if (S == 1 && WT == 7) POOL_LN(1, 7);
   else if (S == 1) POOL_LN(1, 4);

@@ -570,6 +570,7 @@ class _Branches:
 # conv pool + LayerNorm of the q/k/v branches in one launch where dcc_pool_ln_fwd applies (bf16, head_dim 96);
 # DCC_FUSED_POOL_LN=0 keeps the two-kernel path for A/B runs
 FUSED_POOL_LN = os.environ.get("DCC_FUSED_POOL_LN", "1") != "0"
+FUSED_KAUG = os.environ.get("DCC_FUSED_KAUG", "1") != "0"   # the k pool kernel writes the rel-pos one-hot key columns too
 # forward rel-pos inner products per 64-row tile on the matrix cores, P never in HBM (dcc_relpos_aug_fwd_mfma, bf16);
 # DCC_FUSED_RELPOS=0 keeps the stacked-table GEMM + gather
 FUSED_RELPOS = os.environ.get("DCC_FUSED_RELPOS", "1") != "0"
@@ -606,6 +607,7 @@ class MvitAttnCoreFn(torch.autograd.Function):
         Kf = torch.empty((B, Nk, H, DQK), device=qkv.device, dtype=dt)
         Vn = torch.empty((B, Nk, H, D), device=qkv.device, dtype=dt)
         stats = {}
+        kaug_done = False
         # forward: the three fused pool + LayerNorm kernels are short now (24-47 us at stage 2) and the fork / join events cost more
         # than the overlap returns (VideoEncoder forward 13.13 -> 12.87 ms without side streams); the backward keeps them
         br = _Branches(qkv.device, enabled=_BRANCH_STREAMS_FWD)
@@ -615,7 +617,9 @@ class MvitAttnCoreFn(torch.autograd.Function):
             with br.stream(i):
                 fused = None
                 if FUSED_POOL_LN and K.pool_ln_supported(qkv5[:, :, i], geo[name]):
-                    fused = K.pool_ln_fwd(qkv5[:, :, i], geo[name], w.detach().reshape(D, 27), gam.detach(), bet.detach(), eps, dst)
+                    fused = K.pool_ln_fwd(qkv5[:, :, i], geo[name], w.detach().reshape(D, 27), gam.detach(), bet.detach(), eps, dst,
+                                          aug=A if (name == "k" and FUSED_KAUG) else 0)   # the k pool writes the one-hot key augmentation too
+                    kaug_done = kaug_done or (name == "k" and FUSED_KAUG and fused is not None)
                 if fused is not None:
                     conv[name], m_, r_ = fused
                 else:
@@ -643,7 +647,8 @@ class MvitAttnCoreFn(torch.autograd.Function):
             P = K.gemm(q2d, Rcat)
             K.relpos_gather(Qf, P, idx, dims_q, scale)
             del P
-        K.relpos_kaug(Kf, dims_q)
+        if not kaug_done:
+            K.relpos_kaug(Kf, dims_q)
         residual = rope is None
         O, lse = K.attn_fwd(Qf, Kf, Vn, scale=scale, residual=residual, res_start=1)
         ctx.save_for_backward(qkv, conv["q"], conv["k"], conv["v"], mq, rq, mk, rk, mv, rv, Qf, Kf, Vn, O, lse,

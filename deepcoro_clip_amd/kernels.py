@@ -338,10 +338,11 @@ def pool_ln_supported(x: torch.Tensor, g: PoolGeom) -> bool:
 
 
 def pool_ln_fwd(x: torch.Tensor, g: PoolGeom, weight: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
-                out: torch.Tensor):
+                out: torch.Tensor, aug: int = 0):
     """Depthwise-conv pool of x ([B, N_in, H, 96] view) + LayerNorm over the head dimension in one launch.
     out: [B*N_out*H, 96] rows (row stride free, e.g. the first 96 columns of the [.., DQK] attention operand).
-    Returns (conv [B, N_out, H, 96], mean, rstd), or None when the shape is outside the kernel's domain."""
+    aug = 32 / 64: `out` is the first 96 columns of the key operand [.., 96 + aug]; the one-hot rel-pos key augmentation is written
+    behind it (replaces relpos_kaug).  Returns (conv [B, N_out, H, 96], mean, rstd), or None outside the kernel's domain."""
     L.require_cuda(x, weight, gamma, beta, out)
     assert x.shape == (g.B, g.n_in, g.H, g.C) and pool_ln_supported(x, g)
     rows = g.B * g.n_out * g.H
@@ -352,7 +353,7 @@ def pool_ln_fwd(x: torch.Tensor, g: PoolGeom, weight: torch.Tensor, gamma: torch
     mean = torch.empty(rows, device=x.device, dtype=torch.float32)
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
     if not L.try_call("dcc_pool_ln_fwd", L.ptr(x), L.ptr(conv), L.ptr(out), out.stride(0), L.ptr(weight), L.ptr(gamma), L.ptr(beta),
-                      L.ptr(mean), L.ptr(rstd), g.dims(), _pool_strides(x, conv), float(eps), L.dt(x), L.stream()):
+                      L.ptr(mean), L.ptr(rstd), g.dims(), _pool_strides(x, conv), float(eps), int(aug), L.dt(x), L.stream()):
         return None  # outside the fused kernel's index range (very large batches): the caller runs conv + LayerNorm
     return conv, mean, rstd
 

@@ -153,9 +153,10 @@ int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* argmax, const 
  * (torchvision MultiscaleAttention pool_q / pool_k / pool_v = Pool(conv, norm), called from models/video_encoder.py:232-253).
  * bf16, head_dim 96, spatial stride 1/2/4/8.  y = conv output (saved for the LayerNorm backward, y-strides of `strides`),
  * o = LayerNorm(y) rows in (b, n, h) order with row stride ldo (elements), mean / rstd fp32 [B*No*H].
+ * aug = 32 / 64 (k pool): the one-hot rel-pos key augmentation (dcc_relpos_kaug) is written to columns 96 .. 96 + aug of the o rows too.
  * DCC_ERR_UNSUPPORTED outside that domain: use dcc_pool_fwd + dcc_layernorm_fwd. */
 int dcc_pool_ln_fwd(const void* x, void* y, void* o, int64_t ldo, const float* w, const float* gamma, const float* beta,
-                    float* mean, float* rstd, const int* dims, const int64_t* strides, float eps, int dtype, void* stream);
+                    float* mean, float* rstd, const int* dims, const int64_t* strides, float eps, int aug, int dtype, void* stream);
 int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const uint8_t* argmax, const int* dims,
                       const int64_t* strides, int mode, int dtype, int grad_dtype, void* stream);
 int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, float* workspace, const int* dims,

@@ -168,6 +168,29 @@ def test_fused_pool_layernorm_fwd(stride, thw, H, B, ldo):
     assert _rel(mean.cpu(), conv.float().cpu().mean(-1).reshape(-1)) < 1e-4
 
 
+@pytest.mark.parametrize("stride,thw,H,B,A", [((1, 2, 2), (8, 14, 14), 4, 2, 32), ((1, 1, 1), (8, 14, 14), 8, 2, 64),
+                                             ((1, 8, 8), (8, 56, 56), 1, 1, 32), ((1, 4, 4), (8, 56, 56), 2, 1, 64)])
+def test_k_pool_writes_the_one_hot_key_augmentation(stride, thw, H, B, A):
+    """The k pool's fused kernel also writes the rel-pos one-hot columns behind the key (dcc_relpos_kaug's job): identical bytes."""
+    from deepcoro_clip_amd import kernels as K
+
+    C = 96
+    g = _gen(17)
+    geo = K.PoolGeom(B, H, C, thw, (3, 3, 3), stride, (1, 1, 1), True)
+    qkv = (torch.randn(B, geo.n_in, 3, H, C, generator=g) * 0.7).bfloat16().cuda()
+    w = (torch.randn(C, 27, generator=g) * 0.2).cuda()
+    gam = (torch.rand(C, generator=g) + 0.5).cuda(); bet = (torch.randn(C, generator=g) * 0.1).cuda()
+    k_thw = geo.out_thw
+    assert sum(k_thw) <= A
+    Kf = torch.full((B, geo.n_out, H, C + A), 7.0, device="cuda", dtype=torch.bfloat16)
+    K.pool_ln_fwd(qkv[:, :, 1], geo, w, gam, bet, 1e-6, Kf.view(-1, C + A)[:, :C], aug=A)
+    ref = torch.full_like(Kf, 7.0)
+    ref[..., :C] = Kf[..., :C]
+    dims = K.relpos_dims(B, H, C, A, 8, (1, 1, 1), k_thw, (1, 1, 1))   # only the key grid matters to kaug
+    K.relpos_kaug(ref, dims)
+    assert torch.equal(Kf, ref)
+
+
 def test_specialised_entries_report_unsupported_without_raising():
     """The fused pool + LayerNorm entry has a general HIP counterpart: outside its domain it returns DCC_ERR_UNSUPPORTED, which
     `try_call` turns into False (the caller then launches conv + LayerNorm); argument errors still raise."""
