@@ -205,7 +205,7 @@ def test_specialised_entries_report_unsupported_without_raising():
     w = torch.randn(96, 27, device="cuda"); g_ = torch.ones(96, device="cuda"); b_ = torch.zeros(96, device="cuda")
     m = torch.empty(geo.n_out, device="cuda"); r = torch.empty(geo.n_out, device="cuda")
     args = (L.ptr(x), L.ptr(y), L.ptr(o), 96, L.ptr(w), L.ptr(g_), L.ptr(b_), L.ptr(m), L.ptr(r), geo.dims(),
-            K._pool_strides(x, y), 1e-6, L.dt(x), L.stream())
+            K._pool_strides(x, y), 1e-6, 0, L.dt(x), L.stream())
     assert L.try_call("dcc_pool_ln_fwd", *args) is False
     with pytest.raises(DccError):
         L.try_call("dcc_pool_ln_fwd", None, *args[1:])
