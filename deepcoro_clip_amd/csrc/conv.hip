@@ -786,11 +786,26 @@ __device__ __forceinline__ void kaug_row_store(bf16_t* orow_l0, int l, int aug, 
   if (per > 2) dst[1] = v[1];
 }
 
+// one pooling branch of a launch; blockIdx.y picks between two branches of identical geometry (the k and v pools of a block run
+// as ONE grid: each alone fills a third of the chip at stage 2, together they take the time of one)
+struct PoolLnBr {
+  const bf16_t* x; bf16_t* y; bf16_t* o; int64_t ldo;
+  const float* w; const float* gamma; const float* beta; float* mean; float* rstd; int aug;
+};
+
 template <int S, int WT, int PD>
-__global__ __launch_bounds__(256, PD == 0 ? 4 : 2) void dw3_ln_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, bf16_t* __restrict__ o,
-                                                     int64_t ldo, const float* __restrict__ w, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, float eps, RunGeom r, int aug) {
+__global__ __launch_bounds__(256, PD == 0 ? 4 : 2) void dw3_ln_kernel(PoolLnBr br0, PoolLnBr br1, float eps, RunGeom r) {
+  const PoolLnBr& br = blockIdx.y ? br1 : br0;
+  const bf16_t* __restrict__ x = br.x;
+  bf16_t* __restrict__ y = br.y;
+  bf16_t* __restrict__ o = br.o;
+  const int64_t ldo = br.ldo;
+  const float* __restrict__ w = br.w;
+  const float* __restrict__ gamma = br.gamma;
+  const float* __restrict__ beta = br.beta;
+  float* __restrict__ mean = br.mean;
+  float* __restrict__ rstd = br.rstd;
+  const int aug = br.aug;
   constexpr int NC = (WT - 1) * S + 3;
   __shared__ f32x4 wA[27 * 16];   // channels 6l .. 6l+3 of tap k at [k * 16 + l]
   __shared__ f32x2 wB[27 * 16];   // channels 6l+4, 6l+5
@@ -1746,36 +1761,37 @@ extern "C" int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* arg
   return dcc_check_launch();
 }
 
-// Fused depthwise-conv pool + LayerNorm over the head dimension (bf16, C == 96, kernel 3x3x3 / padding 1 / temporal
-// stride 1 / spatial stride 1, 2, 4 or 8).  y: conv output [B,No,H,C] (y-strides), o: LayerNorm(y) rows [(b,n,h)] with row
-// stride ldo, mean / rstd fp32 per row.  DCC_ERR_UNSUPPORTED outside that domain (callers use dcc_pool_fwd + dcc_layernorm_fwd).
-extern "C" int dcc_pool_ln_fwd(const void* x, void* y, void* o, int64_t ldo, const float* w, const float* gamma,
-                               const float* beta, float* mean, float* rstd, const int* dims, const int64_t* strides, float eps,
-                               int aug, int dtype, void* stream) {
-  if (!x || !y || !o || !w || !gamma || !beta || !mean || !rstd || !dims || !strides) return DCC_ERR_ARG;
+static int pool_ln_launch(const PoolLnBr& b0, const PoolLnBr& b1, int nbr, const int* dims, const int64_t* strides, float eps, int dtype,
+                          hipStream_t s) {
   if (dtype != DCC_BF16) return DCC_ERR_UNSUPPORTED;
   PoolGeom g = make_geom(dims, strides);
   if (g.B <= 0 || g.H <= 0 || g.T <= 0 || g.Hs <= 0 || g.Ws <= 0) return DCC_ERR_ARG;
   if (g.C != 96) return DCC_ERR_UNSUPPORTED;
-  if (aug != 0 && aug != 32 && aug != 64) return DCC_ERR_ARG;
-  if (aug && (ldo < 96 + aug || g.To + g.Ho + g.Wo > aug || (ldo % 2))) return DCC_ERR_UNSUPPORTED;
   const int S = dw3_stride(g, 2);
   if (S == 0) return DCC_ERR_UNSUPPORTED;
-  const int64_t st[] = {g.sxb, g.sxn, g.sxh, g.syb, g.syn, g.syh, ldo};
+  const int64_t st[] = {g.sxb, g.sxn, g.sxh, g.syb, g.syn, g.syh};
   for (int64_t v : st)
     if (v % 2) return DCC_ERR_UNSUPPORTED;  // 4-byte aligned 12-byte accesses
-  if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)o)) & 3) return DCC_ERR_UNSUPPORTED;
+  const PoolLnBr* bs[2] = {&b0, &b1};
+  for (int i = 0; i < nbr; ++i) {
+    const PoolLnBr& b = *bs[i];
+    if (!b.x || !b.y || !b.o || !b.w || !b.gamma || !b.beta || !b.mean || !b.rstd) return DCC_ERR_ARG;
+    if (b.aug != 0 && b.aug != 32 && b.aug != 64) return DCC_ERR_ARG;
+    if ((b.ldo % 2) || (b.aug && (b.ldo < 96 + b.aug || g.To + g.Ho + g.Wo > b.aug))) return DCC_ERR_UNSUPPORTED;
+    if ((((uintptr_t)b.x) | ((uintptr_t)b.y) | ((uintptr_t)b.o)) & 3) return DCC_ERR_UNSUPPORTED;
+  }
   const int WT = (S == 1 && g.Wo % 7 == 0) ? 7 : 4;
   RunGeom r = make_run_geom(g, 6, WT);
   if (!set_spans(r, 2, 2)) return DCC_ERR_UNSUPPORTED;
   const int items = r.runs + (g.has_cls ? g.B * g.H : 0);
-  const dim3 grid((items + 15) / 16);
-  hipStream_t s = (hipStream_t)stream;
+  unsigned gx = (items + 15) / 16;
+  if (nbr == 2) gx = (gx + 7) & ~7u;   // both y slices start on XCD 0: the XCD-contiguous order holds per slice (extra blocks exit)
+  const dim3 grid(gx, nbr);
   static const int pd = getenv("DCC_POOL_LN_PD") ? atoi(getenv("DCC_POOL_LN_PD")) : 1;  // A/B knob of tools/pool_bench.py
 #define POOL_LN(S_, WT_)                                                                                                        \
   do {                                                                                                                          \
-    if (pd == 0) hipLaunchKernelGGL((dw3_ln_kernel<S_, WT_, 0>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)o, ldo, w, gamma, beta, mean, rstd, eps, r, aug); \
-    else hipLaunchKernelGGL((dw3_ln_kernel<S_, WT_, 1>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)o, ldo, w, gamma, beta, mean, rstd, eps, r, aug); \
+    if (pd == 0) hipLaunchKernelGGL((dw3_ln_kernel<S_, WT_, 0>), grid, dim3(256), 0, s, b0, b1, eps, r); \
+    else hipLaunchKernelGGL((dw3_ln_kernel<S_, WT_, 1>), grid, dim3(256), 0, s, b0, b1, eps, r); \
   } while (0)
   if (S == 1 && WT == 7) POOL_LN(1, 7);
   else if (S == 1) POOL_LN(1, 4);
@@ -1784,6 +1800,28 @@ extern "C" int dcc_pool_ln_fwd(const void* x, void* y, void* o, int64_t ldo, con
   else POOL_LN(8, 4);
 #undef POOL_LN
   return dcc_check_launch();
+}
+
+// Fused depthwise-conv pool + LayerNorm over the head dimension (bf16, C == 96, kernel 3x3x3 / padding 1 / temporal
+// stride 1 / spatial stride 1, 2, 4 or 8).  y: conv output [B,No,H,C] (y-strides), o: LayerNorm(y) rows [(b,n,h)] with row
+// stride ldo, mean / rstd fp32 per row.  DCC_ERR_UNSUPPORTED outside that domain (callers use dcc_pool_fwd + dcc_layernorm_fwd).
+extern "C" int dcc_pool_ln_fwd(const void* x, void* y, void* o, int64_t ldo, const float* w, const float* gamma,
+                               const float* beta, float* mean, float* rstd, const int* dims, const int64_t* strides, float eps,
+                               int aug, int dtype, void* stream) {
+  if (!dims || !strides) return DCC_ERR_ARG;
+  const PoolLnBr b{(const bf16_t*)x, (bf16_t*)y, (bf16_t*)o, ldo, w, gamma, beta, mean, rstd, aug};
+  return pool_ln_launch(b, b, 1, dims, strides, eps, dtype, (hipStream_t)stream);
+}
+
+// Two pools of identical geometry and strides (a block's k and v) in one launch; ptrs = {x, y, o, w, gamma, beta, mean, rstd} per branch.
+extern "C" int dcc_pool_ln_fwd2(const void* const* ptrs0, const void* const* ptrs1, int64_t ldo0, int64_t ldo1, int aug0, int aug1,
+                                const int* dims, const int64_t* strides, float eps, int dtype, void* stream) {
+  if (!ptrs0 || !ptrs1 || !dims || !strides) return DCC_ERR_ARG;
+  auto mk = [](const void* const* p, int64_t ldo, int aug) {
+    return PoolLnBr{(const bf16_t*)p[0], (bf16_t*)p[1], (bf16_t*)p[2], ldo, (const float*)p[3], (const float*)p[4], (const float*)p[5],
+                    (float*)p[6], (float*)p[7], aug};
+  };
+  return pool_ln_launch(mk(ptrs0, ldo0, aug0), mk(ptrs1, ldo1, aug1), 2, dims, strides, eps, dtype, (hipStream_t)stream);
 }
 
 // dy has the y-strides, dx the x-strides. grad_dtype = element type of dy (T or fp32).

@@ -571,6 +571,7 @@ class _Branches:
 # DCC_FUSED_POOL_LN=0 keeps the two-kernel path for A/B runs
 FUSED_POOL_LN = os.environ.get("DCC_FUSED_POOL_LN", "1") != "0"
 FUSED_KAUG = os.environ.get("DCC_FUSED_KAUG", "1") != "0"   # the k pool kernel writes the rel-pos one-hot key columns too
+FUSED_KV_PAIR = os.environ.get("DCC_FUSED_KV_PAIR", "1") != "0"   # k and v pools of a block in one launch (forward, single stream)
 # forward rel-pos inner products per 64-row tile on the matrix cores, P never in HBM (dcc_relpos_aug_fwd_mfma, bf16);
 # DCC_FUSED_RELPOS=0 keeps the stacked-table GEMM + gather
 FUSED_RELPOS = os.environ.get("DCC_FUSED_RELPOS", "1") != "0"
@@ -611,9 +612,22 @@ class MvitAttnCoreFn(torch.autograd.Function):
         # forward: the three fused pool + LayerNorm kernels are short now (24-47 us at stage 2) and the fork / join events cost more
         # than the overlap returns (VideoEncoder forward 13.13 -> 12.87 ms without side streams); the backward keeps them
         br = _Branches(qkv.device, enabled=_BRANCH_STREAMS_FWD)
+        pair_done = False
+        if (FUSED_POOL_LN and FUSED_KV_PAIR and not br.side and K.pool_ln_supported(qkv5[:, :, 1], geo["k"])):
+            # k and v pools (same geometry, same strides) as ONE grid: each alone under-fills the chip at stage 2
+            pair = K.pool_ln_fwd_pair((qkv5[:, :, 1], qkv5[:, :, 2]), geo["k"], (wk.detach().reshape(D, 27), wv.detach().reshape(D, 27)),
+                                      (gk.detach(), gv.detach()), (bk.detach(), bv.detach()), eps,
+                                      (Kf.view(-1, DQK)[:, :D], Vn.view(-1, D)), augs=(A if FUSED_KAUG else 0, 0))
+            if pair is not None:
+                (conv["k"], mk_, rk_), (conv["v"], mv_, rv_) = pair
+                stats["k"], stats["v"] = (mk_, rk_), (mv_, rv_)
+                kaug_done = FUSED_KAUG
+                pair_done = True
         for i, (name, w, gam, bet, dst) in enumerate((("q", wq, gq, bq, Qf.view(-1, DQK)[:, :D]),
                                                       ("k", wk, gk, bk, Kf.view(-1, DQK)[:, :D]),
                                                       ("v", wv, gv, bv, Vn.view(-1, D)))):
+            if pair_done and name != "q":
+                continue
             with br.stream(i):
                 fused = None
                 if FUSED_POOL_LN and K.pool_ln_supported(qkv5[:, :, i], geo[name]):

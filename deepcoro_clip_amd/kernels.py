@@ -358,6 +358,26 @@ def pool_ln_fwd(x: torch.Tensor, g: PoolGeom, weight: torch.Tensor, gamma: torch
     return conv, mean, rstd
 
 
+def pool_ln_fwd_pair(xs, g: PoolGeom, weights, gammas, betas, eps: float, outs, augs=(0, 0)):
+    """Two fused pools of identical geometry and input strides (a block's k and v branches) in one launch.
+    Returns ((conv, mean, rstd), (conv, mean, rstd)) or None outside the kernel's domain."""
+    L.require_cuda(*xs, *weights, *gammas, *betas, *outs)
+    assert xs[0].stride() == xs[1].stride() and xs[0].shape == xs[1].shape == (g.B, g.n_in, g.H, g.C)
+    rows = g.B * g.n_out * g.H
+    res, ptrs = [], []
+    for x, w, ga, be, out in zip(xs, weights, gammas, betas, outs):
+        assert pool_ln_supported(x, g) and out.shape == (rows, g.C) and out.stride(1) == 1 and out.dtype == x.dtype
+        assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == g.C * 27
+        conv = torch.empty((g.B, g.n_out, g.H, g.C), device=x.device, dtype=x.dtype)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        res.append((conv, mean, rstd))
+        ptrs.append((ctypes.c_void_p * 8)(*[L.ptr(t) for t in (x, conv, out, w, ga, be, mean, rstd)]))
+    ok = L.try_call("dcc_pool_ln_fwd2", ptrs[0], ptrs[1], outs[0].stride(0), outs[1].stride(0), int(augs[0]), int(augs[1]),
+                    g.dims(), _pool_strides(xs[0], res[0][0]), float(eps), L.dt(xs[0]), L.stream())
+    return tuple(res) if ok else None
+
+
 def pool_bwd_data(dy: torch.Tensor, dx: torch.Tensor, g: PoolGeom, weight: torch.Tensor | None,
                   argmax: torch.Tensor | None = None):
     """dx (a [B,N_in,H,C] view, e.g. a slice of the dqkv buffer) is overwritten."""

@@ -157,6 +157,10 @@ int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* argmax, const 
  * DCC_ERR_UNSUPPORTED outside that domain: use dcc_pool_fwd + dcc_layernorm_fwd. */
 int dcc_pool_ln_fwd(const void* x, void* y, void* o, int64_t ldo, const float* w, const float* gamma, const float* beta,
                     float* mean, float* rstd, const int* dims, const int64_t* strides, float eps, int aug, int dtype, void* stream);
+/* Two pools of identical geometry and strides (a block's k and v) in ONE launch of the same kernel; ptrs0 / ptrs1 =
+ * {x, y, o, w, gamma, beta, mean, rstd} of each branch, ldo / aug per branch. */
+int dcc_pool_ln_fwd2(const void* const* ptrs0, const void* const* ptrs1, int64_t ldo0, int64_t ldo1, int aug0, int aug1,
+                     const int* dims, const int64_t* strides, float eps, int dtype, void* stream);
 int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const uint8_t* argmax, const int* dims,
                       const int64_t* strides, int mode, int dtype, int grad_dtype, void* stream);
 int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, float* workspace, const int* dims,

@@ -191,6 +191,29 @@ def test_k_pool_writes_the_one_hot_key_augmentation(stride, thw, H, B, A):
     assert torch.equal(Kf, ref)
 
 
+@pytest.mark.parametrize("stride,thw,H,B", [((1, 2, 2), (8, 14, 14), 4, 3), ((1, 8, 8), (8, 56, 56), 1, 2), ((1, 1, 1), (4, 7, 7), 8, 2)])
+def test_k_and_v_pools_in_one_launch_equal_two_launches(stride, thw, H, B):
+    from deepcoro_clip_amd import kernels as K
+
+    C, A = 96, 32
+    g = _gen(19)
+    geo = K.PoolGeom(B, H, C, thw, (3, 3, 3), stride, (1, 1, 1), True)
+    qkv = (torch.randn(B, geo.n_in, 3, H, C, generator=g) * 0.7).bfloat16().cuda()
+    ws = [(torch.randn(C, 27, generator=g) * 0.2).cuda() for _ in range(2)]
+    gs = [(torch.rand(C, generator=g) + 0.5).cuda() for _ in range(2)]
+    bs = [(torch.randn(C, generator=g) * 0.1).cuda() for _ in range(2)]
+    rows = B * geo.n_out * H
+    Kf = torch.full((rows, C + A), 7.0, device="cuda", dtype=torch.bfloat16); Vn = torch.empty(rows, C, device="cuda", dtype=torch.bfloat16)
+    Kf2 = Kf.clone(); Vn2 = Vn.clone()
+    pair = K.pool_ln_fwd_pair((qkv[:, :, 1], qkv[:, :, 2]), geo, ws, gs, bs, 1e-6, (Kf[:, :C], Vn), augs=(A, 0))
+    assert pair is not None
+    one_k = K.pool_ln_fwd(qkv[:, :, 1], geo, ws[0], gs[0], bs[0], 1e-6, Kf2[:, :C], aug=A)
+    one_v = K.pool_ln_fwd(qkv[:, :, 2], geo, ws[1], gs[1], bs[1], 1e-6, Vn2)
+    assert torch.equal(Kf, Kf2) and torch.equal(Vn, Vn2)
+    for (c, m, r), (c2, m2, r2) in zip(pair, (one_k, one_v)):
+        assert torch.equal(c, c2) and torch.equal(m, m2) and torch.equal(r, r2)
+
+
 def test_specialised_entries_report_unsupported_without_raising():
     """The fused pool + LayerNorm entry has a general HIP counterpart: outside its domain it returns DCC_ERR_UNSUPPORTED, which
     `try_call` turns into False (the caller then launches conv + LayerNorm); argument errors still raise."""
