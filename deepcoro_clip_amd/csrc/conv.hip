@@ -1763,6 +1763,12 @@ extern "C" int dcc_pool_fwd(const void* x, void* y, const float* w, uint8_t* arg
 
 static int pool_ln_launch(const PoolLnBr& b0, const PoolLnBr& b1, int nbr, const int* dims, const int64_t* strides, float eps, int dtype,
                           hipStream_t s) {
+  const PoolLnBr* bs[2] = {&b0, &b1};
+  for (int i = 0; i < nbr; ++i) {   // argument errors before domain checks
+    const PoolLnBr& b = *bs[i];
+    if (!b.x || !b.y || !b.o || !b.w || !b.gamma || !b.beta || !b.mean || !b.rstd) return DCC_ERR_ARG;
+    if (b.aug != 0 && b.aug != 32 && b.aug != 64) return DCC_ERR_ARG;
+  }
   if (dtype != DCC_BF16) return DCC_ERR_UNSUPPORTED;
   PoolGeom g = make_geom(dims, strides);
   if (g.B <= 0 || g.H <= 0 || g.T <= 0 || g.Hs <= 0 || g.Ws <= 0) return DCC_ERR_ARG;
@@ -1772,11 +1778,8 @@ static int pool_ln_launch(const PoolLnBr& b0, const PoolLnBr& b1, int nbr, const
   const int64_t st[] = {g.sxb, g.sxn, g.sxh, g.syb, g.syn, g.syh};
   for (int64_t v : st)
     if (v % 2) return DCC_ERR_UNSUPPORTED;  // 4-byte aligned 12-byte accesses
-  const PoolLnBr* bs[2] = {&b0, &b1};
   for (int i = 0; i < nbr; ++i) {
     const PoolLnBr& b = *bs[i];
-    if (!b.x || !b.y || !b.o || !b.w || !b.gamma || !b.beta || !b.mean || !b.rstd) return DCC_ERR_ARG;
-    if (b.aug != 0 && b.aug != 32 && b.aug != 64) return DCC_ERR_ARG;
     if ((b.ldo % 2) || (b.aug && (b.ldo < 96 + b.aug || g.To + g.Ho + g.Wo > b.aug))) return DCC_ERR_UNSUPPORTED;
     if ((((uintptr_t)b.x) | ((uintptr_t)b.y) | ((uintptr_t)b.o)) & 3) return DCC_ERR_UNSUPPORTED;
   }
