@@ -609,7 +609,7 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
     const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, variant == 8 ? 256 : 128, variant == 11 ? 3 : 4, st);
     if (rc != DCC_ERR_UNSUPPORTED) return rc;
   }
-  // Measured on MI355X (tools/gemm_bench.py, profiles/r02_gemm_bench.txt): forward GEMMs with a short reduction and a
+  // Measured on MI355X (tools/gemm_bench.py, profiles/r02_kernel_bench.txt): forward GEMMs with a short reduction and a
   // wide output (fc1: N = 4C, qkv: N = 3C; K = C <= 768) run 12-15 % faster on 256 x 256 tiles with 8 unspecialised
   // waves (half the L2 -> LDS operand traffic per FLOP) than on the ring kernel's 128 x 128 tiles; N = C outputs, k-major
   // operands and deep reductions stay on the ring kernels (variant 10 disables this choice).
