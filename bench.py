@@ -54,7 +54,8 @@ def build_job(args, device, world, rank):
     torch.manual_seed(0)  # same random-init weights on every rank
     ve = VideoEncoder(backbone="mvit", num_frames=args.frames, spatial_size=(args.size, args.size), pretrained=False,
                       freeze_ratio=1.0, dropout=0.0, token_pooling_mode=args.pooling, attention_pool_dropout=0.0,
-                      compute_dtype=dtype, stochastic_depth_prob=0.0).to(device)  # dropout 0, stochastic depth 0
+                      compute_dtype=dtype, stochastic_depth_prob=0.0,  # dropout 0, stochastic depth 0
+                      use_rope=args.rope, per_video_pool=False, gemm_dtype=args.gemm_dtype).to(device)
     te = TextEncoder(dropout=0.0, freeze_ratio=0.0, compute_dtype=dtype,
                      bert_config=dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).to(device)
     ve.train()
@@ -71,9 +72,10 @@ def build_job(args, device, world, rank):
                {"params": list(te.parameters()), "lr": 2e-5, "name": "text_encoder", "weight_decay": 1e-6},
                {"params": [log_temp], "lr": 1e-4, "name": "temperature"}]
     opt = HipAdamW(groups, lr=1e-4)
-    loss_name = "contrastive_ddp" if world > 1 else "contrastive"
+    loss_name = args.loss + ("_ddp" if world > 1 else "")
     cfg = _Cfg(recall_k=[1, 5], ndcg_k=[5], device=device, world_size=world, gradient_accumulation_steps=1,
-               max_grad_norm=5.0, is_ref_device=rank == 0, loss_name=loss_name, scheduler_name="", temperature=0.07)
+               max_grad_norm=5.0, is_ref_device=rank == 0, loss_name=loss_name, scheduler_name="", temperature=0.07,
+               embedding_cache_micro_batch=args.micro_batch)
     runner = VideoContrastiveLearningRunner(config=cfg, wandb_wrapper=None, train_loader=None, val_loader=None,
                                             video_encoder=vew, text_encoder=tew, optimizer=opt, scaler=None,
                                             log_temp=log_temp, lr_scheduler=None,
@@ -124,7 +126,7 @@ def cpu_baseline(args):
     torch.set_num_threads(cores)
     N = max(1, args.videos)
     B = 2 if N == 1 else 1   # bounded sample: 2 single-video studies, or 1 study of N videos (same clip shapes)
-    vo = init_by_name(VideoEncoderOracle(args.frames, (args.size, args.size), token_pooling_mode=args.pooling))
+    vo = init_by_name(VideoEncoderOracle(args.frames, (args.size, args.size), token_pooling_mode=args.pooling, use_rope=args.rope))
     to = init_by_name(TextEncoderOracle())
     lt = torch.nn.Parameter(torch.log(torch.tensor([0.07])))
     opt = torch.optim.AdamW(list(vo.parameters()) + list(to.parameters()) + [lt], lr=1e-4)
@@ -133,9 +135,11 @@ def cpu_baseline(args):
     ids = torch.randint(0, 30522, (B, args.seq), generator=g)
     mask = torch.ones(B, args.seq, dtype=torch.int64)
 
+    loss_fn = (lambda v, t, l: contrastive_loss(v, t, l, gated=True)) if args.loss == "siglip" else contrastive_loss
+
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = contrastive_loss(vo(videos), to(ids, mask), lt)
+        loss = loss_fn(vo(videos), to(ids, mask), lt)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(list(vo.parameters()) + list(to.parameters()), 5.0)
         opt.step()
@@ -169,6 +173,17 @@ def main():
     ap.add_argument("--seq", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--pooling", default="attention", choices=["mean", "attention"])
+    ap.add_argument("--loss", default="contrastive", choices=["contrastive", "siglip"],
+                    help="registry name of the pair loss ('_ddp' is appended for N > 1)")
+    ap.add_argument("--rope", action="store_true", help="3-D RoPE attention in blocks 3-15 (models/video_encoder.py:268-378)")
+    ap.add_argument("--gemm-dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: the video trunk's forward / data-gradient GEMMs on the block-scaled fp8 MFMA (BASELINE configs[4])")
+    ap.add_argument("--micro-batch", type=int, default=0,
+                    help="embedding-cache micro-batch (studies): the batch is encoded in slices of this size, the loss sees all of it")
+    ap.add_argument("--config", default="", choices=["", "siglip4096", "fp8rope32"],
+                    help="presets of BASELINE.json configs[3] / configs[4] per-rank shards (flags given explicitly still win): "
+                         "siglip4096 = 512 single-video studies per rank through the embedding cache (micro-batch 32), SigLIP; "
+                         "fp8rope32 = 4 studies x 8 videos of 32 x 224 x 224, RoPE tokens, fp8 GEMMs")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="runner.use_step_graph: replay forward+backward+clip from a HIP graph (1 rank). auto = only when the "
                          "warm-up calls show the host needs about as long to launch a step as the GPU to run it")
@@ -176,6 +191,12 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-kernels", type=int, default=0, help="print the N slowest timed kernel shapes (stderr)")
     args = ap.parse_args()
+    presets = {"siglip4096": dict(batch=512, videos=1, loss="siglip", micro_batch=32, pooling="mean"),
+               "fp8rope32": dict(batch=4, videos=8, frames=32, rope=True, gemm_dtype="fp8")}
+    given = {a.lstrip("-").split("=")[0].replace("-", "_") for a in sys.argv[1:] if a.startswith("--")}
+    for k, v in presets.get(args.config, {}).items():
+        if k not in given:
+            setattr(args, k, v)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -258,11 +279,15 @@ def main():
             # the binding ceiling is the one whose ideal time is larger, i.e. whose fraction is higher
             bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
             traffic = None  # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process)
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm_traffic.json")
-            if os.path.exists(pmc) and world == 1:
-                rec = json.load(open(pmc))
+            import glob
+            plain = args.gemm_dtype == "bf16" and not args.rope and args.loss == "contrastive" and not args.micro_batch
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm_traffic.json")), reverse=True):
+                if world != 1 or not plain:
+                    break
+                rec = json.load(open(pmc))  # newest round first: the PMC pass of the kernels this tree actually ships
                 if rec.get("workload") == [args.dtype, args.batch, args.videos, args.frames, args.size, args.pooling]:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    break
             roofline = {"bound": bound, "kernel": "bf16 GEMM family (gemm_ring2_kernel / gemm_ring_kernel / gemm_wide_kernel / gemm_kernel)"
                         if args.dtype == "bf16" else "fp32 GEMM family (gemm_kernel)",
                         "achieved": round(tflops if bound == "mfma" else gbs, 2), "peak": peak if bound == "mfma" else HBM_PEAK_GBS,
@@ -324,7 +349,14 @@ def main():
                                    f"S={args.seq}, InfoNCE, AdamW, B={args.batch}/GPU x N={args.videos} videos/study"
                        if args.videos == 1 else
                        f"multi-video CLIP step: MViT-v2-S {args.frames}x{args.size}x{args.size} x N={args.videos} + "
-                       f"{args.pooling} pooling + aggregator, BERT-base S={args.seq}, B={args.batch}/GPU",
+                       f"{args.pooling} pooling + aggregator, BERT-base S={args.seq}, B={args.batch}/GPU"
+                       + (", 3-D RoPE" if args.rope else "") + (", fp8 trunk GEMMs" if args.gemm_dtype == "fp8" else ""),
+                       "extras": {"loss": args.loss, "rope": bool(args.rope), "gemm_dtype": args.gemm_dtype,
+                                  "embedding_cache_micro_batch": args.micro_batch, "preset": args.config},
+                       # `value` counts CLIPS (each with its study's text) per second; a study of N videos forms one
+                       # video-text pair of the loss matrix: both conventions are recorded so rounds stay comparable
+                       "value_convention": "clips/s = studies/s x videos per study",
+                       "study_pairs_per_s": round(pairs_per_step * args.steps / dt, 3),
                        "global_batch": pairs_per_step, "clips_per_step": clips_per_step, "seq_len": args.seq,
                        "parallelism": f"dp{world}", "loss_first": loss0, "loss_last": m["loss"],
                        "step_graph": step_graph,

@@ -1767,8 +1767,10 @@ static int pool_ln_launch(const PoolLnBr& b0, const PoolLnBr& b1, int nbr, const
   for (int i = 0; i < nbr; ++i) {   // argument errors before domain checks
     const PoolLnBr& b = *bs[i];
     if (!b.x || !b.y || !b.o || !b.w || !b.gamma || !b.beta || !b.mean || !b.rstd) return DCC_ERR_ARG;
-    if (b.aug != 0 && b.aug != 32 && b.aug != 64) return DCC_ERR_ARG;
+    if (b.aug < 0 || b.aug % 32) return DCC_ERR_ARG;
   }
+  for (int i = 0; i < nbr; ++i)
+    if (bs[i]->aug > 64) return DCC_ERR_UNSUPPORTED;   // wider one-hot key augmentations (k_t + k_h + k_w > 64): conv + LayerNorm + relpos_kaug
   if (dtype != DCC_BF16) return DCC_ERR_UNSUPPORTED;
   PoolGeom g = make_geom(dims, strides);
   if (g.B <= 0 || g.H <= 0 || g.T <= 0 || g.Hs <= 0 || g.Ws <= 0) return DCC_ERR_ARG;

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_ring_kernel(GemmParams p, Geo geo)
               if (p.flags & GEMM_DGELU) {
                 const bf16x8 a = STREAM_LOAD(reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf16((float)a[e]);
+                for (int e = 0; e < 8; ++e) v[e] *= dgelu_for<bf16_t>((float)a[e]);
               }
               if (p.flags & GEMM_RESID) {
                 const TC* rp = R + (int64_t)row * p.ldr + col;
@@ -692,13 +692,13 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
         if (p.flags & GEMM_SAVE_PRE) STREAM_STORE(reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col), mv);
         if (p.flags & GEMM_GELU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_bf16(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = gelu_for<bf16_t>(v[e]);
         }
         if (p.flags & GEMM_DGELU) {
           bf16x8 a = pre[k];
           if (p.flags & GEMM_RESID) a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf16((float)a[e]);
+          for (int e = 0; e < 8; ++e) v[e] *= dgelu_for<bf16_t>((float)a[e]);
         }
         if (p.flags & GEMM_RESID) {
 #pragma unroll

@@ -262,12 +262,12 @@ __global__ __launch_bounds__(WNT, (BN == 128 && NS == 3) ? 4 : 2) void gemm_wide
       }
       if (p.flags & GEMM_GELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_bf16(v[e]);
+        for (int e = 0; e < 8; ++e) v[e] = gelu_for<bf16_t>(v[e]);
       }
       if (p.flags & GEMM_DGELU) {
         const bf16x8 a = STREAM_LOAD(reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)row * p.ldaux + col));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf16((float)a[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= dgelu_for<bf16_t>((float)a[e]);
       }
       if (p.flags & GEMM_RESID) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(X + (int64_t)row * ldxx + col);

@@ -133,6 +133,29 @@ __global__ void mreduce_bwd_kernel(const T* __restrict__ dout, const uint8_t* __
   dx[i] = from_f32<T>(g);
 }
 
+// view-angle embeddings (models/multi_instance_linear_probing.py:142-145,265-269): out[r][l][:] = x[r][l][:] + table[ids[r]][:]
+// for rows r = (study, video), L patch tokens per row (L = 1 for [B, N, D] inputs); fp32
+__global__ void view_embed_add_kernel(const float* __restrict__ x, const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                      float* __restrict__ out, int64_t rows, int L, int D) {
+  const int64_t n = rows * L * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ((int64_t)L * D);
+    const int d = (int)(i % D);
+    out[i] = x[i] + table[ids[r] * D + d];
+  }
+}
+// dtable[ids[r]][:] += sum_l dy[r][l][:]  (one block per row, fp32 atomics: few rows share a class)
+__global__ void view_embed_bwd_kernel(const float* __restrict__ dy, const int64_t* __restrict__ ids, float* __restrict__ dtable,
+                                      int L, int D) {
+  const int64_t r = blockIdx.x;
+  const float* src = dy + r * L * D;
+  float* dst = dtable + ids[r] * D;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float acc = 0.0f;
+    for (int l = 0; l < L; ++l) acc += src[(int64_t)l * D + d];
+    atomicAdd(dst + d, acc);
+  }
+}
 }  // namespace
 
 #define ST (hipStream_t) stream
@@ -201,5 +224,19 @@ extern "C" int dcc_masked_reduce_bwd(const void* dout, const uint8_t* mask, cons
   if (dtype == DCC_BF16) hipLaunchKernelGGL((mreduce_bwd_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)dout, mask, arg, (bf16_t*)dx, B, N, D, mode);
   else if (dtype == DCC_F32) hipLaunchKernelGGL((mreduce_bwd_kernel<float>), g, dim3(256), 0, ST, (const float*)dout, mask, arg, (float*)dx, B, N, D, mode);
   else return DCC_ERR_UNSUPPORTED;
+  return dcc_check_launch();
+}
+
+// view-angle embedding add and its table gradient (ids: int64 [rows], validated on the host: 0 <= id < classes)
+extern "C" int dcc_view_embed_add(const float* x, const int64_t* ids, const float* table, float* out, int64_t rows, int L, int D,
+                                  void* stream) {
+  if (!x || !ids || !table || !out || rows <= 0 || L <= 0 || D <= 0) return DCC_ERR_ARG;
+  hipLaunchKernelGGL(view_embed_add_kernel, dim3(gsm(rows * L * D)), dim3(256), 0, ST, x, ids, table, out, rows, L, D);
+  return dcc_check_launch();
+}
+extern "C" int dcc_view_embed_bwd(const float* dy, const int64_t* ids, float* dtable, int64_t rows, int L, int D, void* stream) {
+  if (!dy || !ids || !dtable || rows <= 0 || L <= 0 || D <= 0) return DCC_ERR_ARG;
+  if (rows > 0x7fffffffLL) return DCC_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(view_embed_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, ST, dy, ids, dtable, L, D);
   return dcc_check_launch();
 }

@@ -9,6 +9,11 @@ for the MI355X node rather than translating torch's reducer:
     per-link bound, so few large messages beat DDP's 25 MiB NVSwitch-era default;
   * a bucket's all-reduce (AVG) is launched from a post-accumulate-grad hook as soon as its last gradient is
     written — RCCL runs it on its own stream, overlapped with the rest of backward; `finish()` joins them;
+  * host cost: the first reduced backward runs one Python hook per parameter and records the order in which gradients
+    arrive; from then on ONE hook per bucket (on the parameter whose gradient arrived last) moves the bucket's stray
+    gradients into the arena and starts its all-reduce — ~10 hook calls per step instead of ~500 on a step whose host
+    enqueue time is the bottleneck.  A bucket whose expected gradients are not all there when its hook fires (the order
+    changed: freezing, unused branches) is deferred to `finish()`; accumulation windows keep the per-parameter hooks;
   * gradient accumulation has torch DDP's `no_sync` semantics: `begin_backward(sync=False)` micro-steps only
     accumulate into the arena, the buckets are reduced once, from the hooks of the window's LAST backward
     (`begin_backward(sync=True)`, the default), so no collective ever overlaps a later in-place accumulate.
@@ -40,6 +45,13 @@ class HipDDP(torch.nn.Module):
         self._pending: list[int] = []
         self._bucket_of: dict[int, int] = {}
         self._hooks_installed = False
+        self._hook_handles: list = []
+        self._mode = "learn"        # "learn": per-parameter hooks, arrival order recorded; "bucket": one hook per bucket;
+        #                             "param": per-parameter hooks for good (accumulation windows)
+        self._arrivals: list[int] = []
+        self._expected: list[list] = []   # per bucket: the parameters whose gradient arrived in the learning backward
+        self._deferred: set[int] = set()
+        self.hook_calls = 0         # Python hook invocations (tests / diagnostics)
         self._sync = True  # reduce from this backward's hooks (False: accumulate-only micro-step of a window)
         # parameters whose gradient nobody zeroes (outside every optimizer group): their arena slot survives
         # attach_grads() and stays attached, so the history keeps accumulating as it does under torch DDP
@@ -98,10 +110,32 @@ class HipDDP(torch.nn.Module):
             p.grad = self._views[id(p)]
         self._handles = []
         if not self._hooks_installed:
-            for p in self._order:
-                p.register_post_accumulate_grad_hook(self._make_hook(p))
-            self._hooks_installed = True
+            self._install_param_hooks()
+        self._fresh = True   # every gradient slot is empty: the precondition of the one-hook-per-bucket mode
         self.begin_backward(sync=True)
+
+    def _install_param_hooks(self):
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = [p.register_post_accumulate_grad_hook(self._make_hook(p)) for p in self._order if p.requires_grad]
+        self._req_sig = tuple(p.requires_grad for p in self._order)
+        self._hooks_installed = True
+
+    def _install_bucket_hooks(self):
+        """One hook per bucket, on the parameter whose gradient arrived last in the recorded backward."""
+        pos = {pid: i for i, pid in enumerate(self._arrivals)}
+        by_id = {id(p): p for p in self._order}
+        self._expected = [[] for _ in self._buckets]
+        last: dict[int, int] = {}
+        for pid in self._arrivals:
+            b = self._bucket_of[pid]
+            self._expected[b].append(by_id[pid])
+            last[b] = pid
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = [by_id[pid].register_post_accumulate_grad_hook(self._make_bucket_hook(b)) for b, pid in last.items()]
+        self._req_sig = tuple(p.requires_grad for p in self._order)
+        self._mode = "bucket"
 
     def begin_backward(self, sync: bool = True):
         """Arm the wrapper for ONE backward pass.  sync=False: a non-final micro-step of a gradient-accumulation window
@@ -110,14 +144,55 @@ class HipDDP(torch.nn.Module):
         callers without accumulation never need this."""
         if self._handles:
             raise RuntimeError("begin_backward() while bucket all-reduces of the previous backward are in flight: call finish()")
+        if not sync or not getattr(self, "_fresh", False):
+            # an accumulation window: gradients of earlier micro-steps sit in the slots, so "the gradient is there" no longer
+            # proves that THIS backward's contribution arrived — count arrivals per parameter, for good
+            if self._mode != "param":
+                self._mode = "param"
+                if self._hooks_installed:
+                    self._install_param_hooks()
+        if self._hooks_installed and self._req_sig != tuple(p.requires_grad for p in self._order):
+            # the trainable set changed (update_freeze_ratio): hooks follow it, the arrival order is learned again
+            if self._mode == "bucket":
+                self._mode = "learn"
+            self._install_param_hooks()
+        self._fresh = False
+        self._arrivals = []
+        self._deferred = set()
         self._sync = bool(sync)
         self._pending = [0] * len(self._buckets)
         for p in self._order:
             if p.requires_grad:
                 self._pending[self._bucket_of[id(p)]] += 1
 
+    def _make_bucket_hook(self, b: int):
+        def hook(_param):
+            self.hook_calls += 1
+            ready = True
+            for q in self._expected[b]:
+                g = q.grad
+                if g is None:
+                    ready = False      # the arrival order changed: leave the bucket to finish()
+                    continue
+                v = self._views[id(q)]
+                if g.data_ptr() != v.data_ptr():
+                    v.copy_(g)
+                    q.grad = v
+            if self.world <= 1 or not self._sync:
+                return
+            if not ready:
+                self._deferred.add(b)
+                return
+            self._pending[b] = 0
+            self._launch(b)
+
+        return hook
+
     def _make_hook(self, p):
         def hook(param):
+            self.hook_calls += 1
+            if self._mode == "learn":
+                self._arrivals.append(id(p))
             v = self._views[id(p)]
             g = param.grad
             if g is not None and g.data_ptr() != v.data_ptr():  # produced elsewhere: move it into the arena
@@ -147,9 +222,26 @@ class HipDDP(torch.nn.Module):
         if self._arena is None:
             return
         for p in self._order:  # parameters without a gradient this step keep the old contract: a zero view
-            if p.requires_grad and p.grad is None:
-                p.grad = self._views[id(p)]
+            if not p.requires_grad:
+                continue
+            v = self._views[id(p)]
+            if p.grad is None:
+                p.grad = v
+            elif self._mode == "bucket" and p.grad.data_ptr() != v.data_ptr():
+                # bucket mode: a gradient that arrived after its bucket's hook (or outside the recorded order) is still
+                # outside the arena; its bucket was deferred below, so nothing has been reduced without it
+                b = self._bucket_of[id(p)]
+                if self.world > 1 and self._sync and self._pending[b] == 0:
+                    raise RuntimeError("HipDDP: a gradient arrived after its bucket had been reduced (the backward order changed "
+                                       "between steps); construct the wrapper again or call begin_backward(sync=False) once to "
+                                       "return to per-parameter hooks")
+                self._deferred.add(b)
+                v.copy_(p.grad)
+                p.grad = v
+        learned = self._mode == "learn" and self._sync and bool(self._arrivals)
         if self.world <= 1:
+            if learned:
+                self._install_bucket_hooks()
             return
         if not self._sync:
             raise RuntimeError("finish() after an accumulate-only backward: the window's last backward must be armed with "
@@ -163,6 +255,8 @@ class HipDDP(torch.nn.Module):
             if buf is not None:
                 buf.div_(self.world)
         self._handles = []
+        if learned:
+            self._install_bucket_hooks()
 
     # ------------------------------------------------------------------------------------------- nn.Module
     def forward(self, *args, **kwargs):

@@ -603,6 +603,9 @@ class MvitAttnCoreFn(torch.autograd.Function):
         q_thw, k_thw = geo["q"].out_thw, geo["k"].out_thw
         Nq, Nk = geo["q"].n_out, geo["k"].n_out
         A = relpos_aug_width(k_thw)
+        if A > 64:  # k_t + k_h + k_w > 64 (e.g. 32 frames x 448^2): the flash kernels are built for D + 32 / D + 64 columns
+            raise NotImplementedError(f"key grid {k_thw}: relative-position augmentation of {A} columns exceeds the attention "
+                                      "kernels' 64 (head_dim 96 + 32 / 64); reduce the clip size or the key stride")
         DQK = D + A
         Qf = torch.empty((B, Nq, H, DQK), device=qkv.device, dtype=dt)
         Kf = torch.empty((B, Nk, H, DQK), device=qkv.device, dtype=dt)
@@ -991,6 +994,27 @@ class MaskedReduceFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d):
         return K.masked_reduce_bwd(_c(d), ctx.mask, ctx.arg, ctx.N, ctx.mode), None, None
+
+
+class ViewEmbedAddFn(torch.autograd.Function):
+    """x + table[ids] broadcast over the patch axis (models/multi_instance_linear_probing.py:265-269)."""
+
+    @staticmethod
+    def forward(ctx, x, ids, table):
+        ctx.save_for_backward(ids)
+        ctx.classes = table.shape[0]
+        return K.view_embed_add(x, ids, _c(table.detach()))
+
+    @staticmethod
+    def backward(ctx, d):
+        (ids,) = ctx.saved_tensors
+        d = _c(d)
+        return d, None, (K.view_embed_bwd(d, ids, ctx.classes) if ctx.needs_input_grad[2] else None)
+
+
+def view_embed_add(x, ids, table):
+    """x: [rows, L, D] fp32; ids: int64 [rows]; table: [classes, D] fp32."""
+    return ViewEmbedAddFn.apply(x, ids, table)
 
 
 def gate(v, u):

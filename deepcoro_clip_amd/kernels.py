@@ -515,6 +515,25 @@ def axpby(x: torch.Tensor, y: torch.Tensor | None = None, a: float = 1.0, b: flo
     return out
 
 
+def resize_frames_u8(frames: torch.Tensor, size: tuple[int, int], frame_idx: torch.Tensor | None = None, n_out: int | None = None,
+                     mean: torch.Tensor | None = None, std: torch.Tensor | None = None, antialias: bool = True,
+                     out_uint8: bool = False) -> torch.Tensor:
+    """uint8 frames [T_in, H_in, W_in, C_in] (C_in 1 or 3) -> [T_out, size[0], size[1], 3]: anti-aliased bilinear resize with
+    optional frame index select (device int32 [T_out]) and per-channel normalisation (fp32 output), or uint8 output."""
+    L.require_cuda(frames, frame_idx, mean, std)
+    assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.is_contiguous() and frames.shape[3] in (1, 3)
+    T_in, H_in, W_in, C_in = frames.shape
+    T_out = int(frame_idx.numel()) if frame_idx is not None else int(n_out or T_in)
+    if frame_idx is not None:
+        assert frame_idx.dtype == torch.int32 and frame_idx.is_contiguous()
+    if mean is not None:
+        assert std is not None and mean.dtype == torch.float32 and std.dtype == torch.float32 and mean.numel() == 3 and std.numel() == 3
+    out = torch.empty((T_out, int(size[0]), int(size[1]), 3), device=frames.device, dtype=torch.uint8 if out_uint8 else torch.float32)
+    L.call("dcc_resize_frames_u8", L.ptr(frames), L.ptr(frame_idx), L.ptr(out), L.ptr(mean), L.ptr(std), T_in, H_in, W_in, C_in,
+           T_out, int(size[0]), int(size[1]), int(antialias), int(out_uint8), L.stream())
+    return out
+
+
 def u8_normalize(frames: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
     """uint8 [..., C] frames -> fp32 (x - mean[c]) / std[c]."""
     L.require_cuda(frames, mean, std)
@@ -790,11 +809,19 @@ def auto_balance_weights(counts: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_ENT_INIT: dict = {}
+
+
 def entropy_reg(z: torch.Tensor, dz: torch.Tensor | None, weight: float, thr: float, scal: torch.Tensor) -> torch.Tensor:
     """scal[0] += weight * relu(thr - mean row entropy of softmax(z)); dz += gradient.  Returns ent = {sum H, min H, max H, -}."""
     L.require_cuda(z, dz, scal)
     B, M = z.shape
-    ent = torch.tensor([0.0, float("inf"), 0.0, 0.0], dtype=torch.float32).to(z.device, non_blocking=True)
+    # {0, +inf, 0, 0} from a per-device constant by a device-to-device copy: a pageable host-to-device copy per call is
+    # illegal inside HIP-graph capture and silently sent SigLIP + entropy regularisation back to eager (ADVICE r2)
+    init = _ENT_INIT.get(z.device)
+    if init is None:
+        init = _ENT_INIT[z.device] = torch.tensor([0.0, float("inf"), 0.0, 0.0], dtype=torch.float32, device=z.device)
+    ent = init.clone()
     L.call("dcc_entropy_reg", L.ptr(z), L.ptr(dz), B, M, float(weight), float(thr), L.ptr(ent), L.ptr(scal), L.stream())
     return ent
 
@@ -824,6 +851,27 @@ def clamp01(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(x)
     L.call("dcc_clamp", L.ptr(x), L.ptr(out), x.numel(), 0.0, 1.0, L.stream())
     return out
+
+
+def view_embed_add(x: torch.Tensor, ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """x [rows, L, D] fp32 + table[ids[row]] broadcast over L (view-angle embeddings of the MIL head)."""
+    L.require_cuda(x, ids, table)
+    rows, Lt, D = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and table.dtype == torch.float32 and table.is_contiguous()
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == rows and table.shape[1] == D
+    out = torch.empty_like(x)
+    L.call("dcc_view_embed_add", L.ptr(x), L.ptr(ids), L.ptr(table), L.ptr(out), rows, Lt, D, L.stream())
+    return out
+
+
+def view_embed_bwd(dy: torch.Tensor, ids: torch.Tensor, classes: int) -> torch.Tensor:
+    """Table gradient [classes, D] of view_embed_add: rows of dy summed over L, scattered by class."""
+    L.require_cuda(dy, ids)
+    rows, Lt, D = dy.shape
+    assert dy.dtype == torch.float32 and dy.is_contiguous() and ids.numel() == rows
+    dtable = torch.zeros((classes, D), device=dy.device, dtype=torch.float32)
+    L.call("dcc_view_embed_bwd", L.ptr(dy), L.ptr(ids), L.ptr(dtable), rows, Lt, D, L.stream())
+    return dtable
 
 
 # ------------------------------------------------------------------------------------------ fp8

@@ -9,7 +9,7 @@
 
 The head runs in fp32 (its tensors are tiny next to the trunk's; the reference runs it outside autocast-sensitive code too):
 linears through the fp32 MFMA GEMM, pooling through csrc/mil.hip, attention through the flash kernel with the instance mask as
-an additive key bias.  `num_view_classes > 0` (view-angle embeddings) is not implemented.
+an additive key bias.  View-angle embeddings (`num_view_classes > 0`, reference :142-145,265-269): `dcc_view_embed_add`.
 """
 from __future__ import annotations
 
@@ -44,12 +44,13 @@ class MultiInstanceLinearProbing(nn.Module):
             raise ValueError("head_structure cannot be empty")
         if normalization_strategy not in {"pre_norm", "post_norm"}:
             raise ValueError("normalization_strategy must be 'pre_norm' or 'post_norm'")
-        if num_view_classes > 0:
-            raise NotImplementedError("view-angle embeddings (num_view_classes > 0) are not on the HIP path")
         self.embedding_dim, self.pooling_mode, self.head_structure = embedding_dim, pooling_mode, head_structure
         self.use_cls_token = use_cls_token or "cls_token" in pooling_mode
         self.num_attention_heads, self.separate_video_attention = num_attention_heads, separate_video_attention
         self.normalization_strategy, self.num_view_classes, self.p = normalization_strategy, num_view_classes, dropout
+        if num_view_classes > 0:  # EchoJEPA-style angle embeddings; +1 = the PAD class of missing / padded views (reference :142-145)
+            self.view_embedding = nn.Embedding(num_view_classes + 1, embedding_dim)
+            self.view_pad_id = num_view_classes
         if self.use_cls_token:
             self.cls_token = nn.Parameter(torch.randn(1, 1, embedding_dim))
             mk = lambda: nn.MultiheadAttention(embed_dim=embedding_dim, num_heads=num_attention_heads, dropout=dropout, batch_first=True)  # noqa: E731
@@ -83,6 +84,16 @@ class MultiInstanceLinearProbing(nn.Module):
         if x.ndim == 4 and (self.pooling_mode in {"mean", "max"} or ("mean" in self.pooling_mode and "+" in self.pooling_mode)):
             B, N, L, D = x.shape  # patch tokens with a patch-agnostic pooling rule: average the patches first (reference :246-262)
             x = Fn.masked_mean(x.view(B * N, L, D)).view(B, N, D)
+        if view_ids is not None and self.num_view_classes > 0:  # reference :265-269 (after the patch averaging, broadcast over L)
+            B, N = x.shape[0], x.shape[1]
+            if tuple(view_ids.shape) != (B, N):
+                raise ValueError(f"view_ids shape {tuple(view_ids.shape)} does not match {(B, N)}")
+            ids = view_ids.to(device=x.device, dtype=torch.int64).contiguous()
+            lo, hi = int(ids.min()), int(ids.max())   # nn.Embedding's index check (the kernel trusts the ids)
+            if lo < 0 or hi > self.num_view_classes:
+                raise IndexError(f"view id out of range [0, {self.num_view_classes}]: min {lo}, max {hi}")
+            Lt = x.shape[2] if x.ndim == 4 else 1
+            x = Fn.view_embed_add(x.reshape(B * N, Lt, x.shape[-1]), ids.view(-1), self.view_embedding.weight).view(x.shape)
         pooled = self._pool_instances(x, mask)
         return {name: Fn.linear(pooled, head.weight, head.bias) for name, head in self.heads.items()}
 

@@ -301,17 +301,11 @@ class VideoContrastiveLearningRunner:
         mp = bool(diag.get("multi_positive")) and diag.get("logits") is not None and diag.get("sim") is not None
         if mp:  # weighted log-prob of the positives + mean cosine over the positives (reference :1298-1313)
             pack[10:18] = K.mp_align(diag["logits"], diag["sim"], diag["mp_targets"], diag.get("mp_weights"))
-        capturing = torch.cuda.is_current_stream_capturing()
-        if capturing:  # captured step: the copy node writes this fixed buffer at every replay (_graph_train_step)
-            if getattr(self, "_graph_host", None) is None:
-                raise RuntimeError("graph capture needs runner._graph_host (set by _graph_train_step)")
-            host = self._graph_host
-        else:
-            host = torch.empty(18, dtype=torch.float32, pin_memory=True)
+        # never inside a capture: a replayed step runs its optimizer launch and this metric copy eagerly (_graph_train_step)
+        host = torch.empty(18, dtype=torch.float32, pin_memory=True)
         host.copy_(pack, non_blocking=True)  # the one device->host transfer of the step; waited for on first read
         event = torch.cuda.Event()
-        if not capturing:
-            event.record()
+        event.record()
         n_text = text_emb.shape[0] if text_emb is not None else 0
         lrs = {f"lr/{pg.get('name', str(i))}": pg["lr"]
                for i, pg in enumerate(self.optimizer.param_groups if self.optimizer is not None else [])}
@@ -684,24 +678,36 @@ class VideoContrastiveLearningRunner:
             # every collective below runs on EVERY rank, before the rank-0-only metric computation (a gather inside the
             # is_ref_device branch deadlocks; a packed all-reduce over different key sets corrupts or hangs)
             dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
-            v_local = torch.cat(all_v, 0) if all_v else torch.empty((0, 512), device=dev)
-            t_local = torch.cat(all_t, 0) if all_t else torch.empty((0, 512), device=dev)
+            enc = self.video_encoder.module if hasattr(self.video_encoder, "module") else self.video_encoder
+            width = int(getattr(enc, "embedding_dim", 512))
+            v_local = torch.cat(all_v, 0) if all_v else torch.empty((0, width), device=dev)
+            t_local = torch.cat(all_t, 0) if all_t else torch.empty((0, width), device=dev)
+            if t_local.dim() != 2:   # steps without texts hand out 1-D empties: every rank still joins the gather below
+                t_local = torch.empty((0, width), device=dev, dtype=v_local.dtype)
             v = self._gather_tensor_along_batch(v_local, self.world_size)
-            t = self._gather_tensor_along_batch(t_local, self.world_size) if t_local.dim() == 2 else t_local
+            t = self._gather_tensor_along_batch(t_local, self.world_size)   # unconditional: a collective must not hang on rank-local state
             texts = self._gather_objects(all_texts)
             paths_g = self._gather_objects(all_paths)
             tok = getattr(self.text_encoder.module if hasattr(self.text_encoder, "module") else self.text_encoder,
                           "tokenizer", None)
             retrieval_keys = self._retrieval_metric_keys()
             ret = {k: 0.0 for k in retrieval_keys}   # non-reference ranks: placeholders under the same keys (reference :1023-1033)
-            if _cfg(self.config, "is_ref_device", True) and v.shape[0]:
-                if tok is not None and len(texts) == v.shape[0] and any(x for x in texts):
-                    ret.update(self._unique_text_retrieval(v, texts, paths_g, tok, epoch))
-                elif t.numel() and t.shape[0] == v.shape[0]:
-                    # no report texts / no tokenizer: the in-batch pairs are the ground truth (diagonal)
-                    ret.update(self._retrieval_metrics(compute_similarity_matrix(v, t), torch.arange(v.shape[0])))
+            if _cfg(self.config, "is_ref_device", True):
+                computed = False
+                if v.shape[0]:
+                    if tok is not None and len(texts) == v.shape[0] and any(x for x in texts):
+                        ret.update(self._unique_text_retrieval(v, texts, paths_g, tok, epoch))
+                        computed = True
+                    elif t.numel() and t.shape[0] == v.shape[0]:
+                        # no report texts / no tokenizer: the in-batch pairs are the ground truth (diagonal)
+                        ret.update(self._retrieval_metrics(compute_similarity_matrix(v, t), torch.arange(v.shape[0])))
+                        computed = True
+                if not computed:   # nothing to rank: NaN marks "absent" through the packed all-reduce (same keys on every rank)
+                    ret = {k: float("nan") for k in retrieval_keys}
             out.update({f"{mode}/{k}": float(x) for k, x in ret.items() if k in retrieval_keys})
-        return self._maybe_reduce_metrics(out, rank0_only={f"{mode}/{k}" for k in retrieval_keys})
+        out = self._maybe_reduce_metrics(out, rank0_only={f"{mode}/{k}" for k in retrieval_keys})
+        # retrieval keys the reference rank could not compute are dropped, not reported (and checkpointed) as a real 0.0
+        return {k: v for k, v in out.items() if not (isinstance(v, float) and math.isnan(v) and k.split("/", 1)[-1] in retrieval_keys)}
 
     def _retrieval_metric_keys(self) -> List[str]:
         """The retrieval keys every rank reports at the end of a validation epoch (same order on all ranks)."""

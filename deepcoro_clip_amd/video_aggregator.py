@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from .attention_pool import key_bias
 
 
 class TransformerBlock(nn.Module):
@@ -24,12 +25,14 @@ class TransformerBlock(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
 
     def forward(self, x: torch.Tensor, key_padding_mask=None) -> torch.Tensor:
-        if key_padding_mask is not None:
-            raise NotImplementedError("masked aggregation is unused on the contrastive path")
+        """key_padding_mask: bool [B, N], True = padded video (reference :33-54), or the additive fp32 key bias built from it."""
         a = self.attn
+        kb = key_padding_mask
+        if kb is not None and kb.dtype != torch.float32:
+            kb = key_bias(kb, x.shape[0], x.shape[1], x.device)
         h = Fn.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         att = Fn.multihead_attention(h, h, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
-                                     self.num_heads, self_attn=True, dropout_p=self.p, training=self.training)
+                                     self.num_heads, self_attn=True, dropout_p=self.p, training=self.training, kbias=kb)
         x = Fn.add(x, Fn.dropout(att, self.p, self.training))
         h = Fn.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         if self.training and self.p > 0:
@@ -57,14 +60,20 @@ class EnhancedVideoAggregator(nn.Module):
         nn.init.normal_(self.attn_query, std=0.02)
 
     def forward(self, x: torch.Tensor, mask=None) -> torch.Tensor:
-        """x: [B, N, D] fp32 -> [B, D] fp32."""
-        if mask is not None:
-            raise NotImplementedError("masked aggregation is unused on the contrastive path")
+        """x: [B, N, D] fp32 -> [B, D] fp32.  mask: bool [B, N], True = padded video (reference :105-159): masked keys in
+        every block's self-attention, then a softmax over the VALID videos only; a study without any valid video pools to
+        zeros (the reference's fallback weights valid / sum(valid) are all zero there)."""
         B, N, D = x.shape
         x = Fn.cast(x, torch.float32)
         if self.pos_encoding is not None:
             x = Fn.add(x, self.pos_encoding[:, :N, :].expand(B, N, D))
+        kb = key_bias(mask, B, N, x.device)
         for blk in self.blocks:
-            x = blk(x)
+            x = blk(x, kb)
         x = Fn.layernorm(x, self.final_ln.weight, self.final_ln.bias, self.final_ln.eps)
-        return Fn.qpool(x, self.attn_query)
+        if mask is None:
+            return Fn.qpool(x, self.attn_query)
+        # masked rows get weight 0 (forward and backward), so zero-filling them first (reference :131-132) changes nothing
+        valid = (~mask.to(device=x.device, dtype=torch.bool)).to(torch.uint8).contiguous()
+        scores = Fn.linear(x, self.attn_query.view(1, D)).view(B, N)
+        return Fn.weighted_sum(Fn.masked_softmax(scores, valid), x)

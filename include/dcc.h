@@ -175,6 +175,15 @@ int dcc_dgelu_mul(const void* dy, const void* pre, void* out, int64_t n, int dty
 /* uint8 frames -> (x - mean[c]) / std[c] fp32, channel innermost (v2.Normalize of utils/video.py:278-288 moved to the GPU:
  * the host uploads 1 byte per sample).  n = number of samples (multiple of 4), mean/std device fp32 [C]. */
 int dcc_u8_normalize(const uint8_t* src, float* dst, int64_t n, int C, const float* mean, const float* stdv, void* stream);
+/* Decoded uint8 frames -> the clip tensor the trunk reads, on the GPU (csrc/resize.hip; replaces the host fp32 pipeline of
+ * utils/video.py:246-288: frame index select / last-frame padding, v2.Resize((s, s), antialias=True) = F.interpolate(bilinear,
+ * antialias, align_corners=False), grayscale -> 3 channels, v2.Normalize).  src: uint8 [T_in, H_in, W_in, C_in] (C_in 1 | 3);
+ * frame_idx: device int32 [T_out] source frame per output frame (null = identity); dst: [T_out, H_out, W_out, 3] fp32
+ * ((v - mean[c]) / stdv[c] when mean / stdv are given) or, with out_u8 = 1, uint8 rounded half-to-even and clamped (feeds
+ * dcc_im2col3d_u8, which normalises inside the patch gather).  antialias = 0: plain bilinear. */
+int dcc_resize_frames_u8(const uint8_t* src, const int* frame_idx, void* dst, const float* mean, const float* stdv, int T_in,
+                         int H_in, int W_in, int C_in, int T_out, int H_out, int W_out, int antialias, int out_u8,
+                         void* stream);
 /* torchvision.ops.StochasticDepth(p, "row") of MultiscaleBlock (torchvision mvit.py via models/video_encoder.py:93):
  * out = resid + x * scale[sample] with scale = bernoulli(1-p)/(1-p) per clip; resid may be null (backward). */
 int dcc_scale_rows(const void* x, const float* scale, const void* resid, void* out, int64_t samples,
@@ -219,6 +228,13 @@ int dcc_masked_reduce_fwd(const void* x, const uint8_t* mask, void* out, int* ar
                           void* stream);
 int dcc_masked_reduce_bwd(const void* dout, const uint8_t* mask, const int* arg, void* dx, int B, int N, int D, int mode,
                           int dtype, void* stream);
+/* View-angle embeddings of the MIL head (models/multi_instance_linear_probing.py:142-145 `nn.Embedding(num_view_classes + 1,
+ * D)`, :265-269 `x = x + view_embedding(view_ids)` broadcast over the L patch tokens of a video): out[r][l][:] = x[r][l][:] +
+ * table[ids[r]][:], rows r = (study, video); the backward accumulates dtable[ids[r]][:] += sum_l dy[r][l][:] (fp32 atomics into
+ * a zeroed table gradient).  ids: int64, range-checked by the caller. */
+int dcc_view_embed_add(const float* x, const int64_t* ids, const float* table, float* out, int64_t rows, int L, int D,
+                       void* stream);
+int dcc_view_embed_bwd(const float* dy, const int64_t* ids, float* dtable, int64_t rows, int L, int D, void* stream);
 
 /* ---- contrastive losses (csrc/loss.hip); scal = fp32[8]
  * {0 loss, 1 dlog_temp, 2 dbias, 3 mean diag log-softmax, 4 mean diag cosine, 5 sum ||v||, 6 sum ||t||, 7 -} */

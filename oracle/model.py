@@ -44,14 +44,17 @@ def init_by_name(module: nn.Module, seed: int = 0) -> nn.Module:
     return module
 
 
-def mha_forward(query, key, in_w, in_b, out_w, out_b, num_heads):
-    """batch_first nn.MultiheadAttention(query, key, key) without masks/dropout."""
+def mha_forward(query, key, in_w, in_b, out_w, out_b, num_heads, key_padding_mask=None):
+    """batch_first nn.MultiheadAttention(query, key, key) without dropout; key_padding_mask: bool [B, Lk], True = ignored
+    (nn.MultiheadAttention's key_padding_mask: -inf on the masked keys' scores)."""
     B, Lq, E = query.shape
     hd = E // num_heads
     q = F.linear(query, in_w[:E], in_b[:E]).view(B, Lq, num_heads, hd).transpose(1, 2)
     k = F.linear(key, in_w[E:2 * E], in_b[E:2 * E]).view(B, -1, num_heads, hd).transpose(1, 2)
     v = F.linear(key, in_w[2 * E:], in_b[2 * E:]).view(B, -1, num_heads, hd).transpose(1, 2)
     a = (q @ k.transpose(-2, -1)) / math.sqrt(hd)
+    if key_padding_mask is not None:
+        a = a.masked_fill(key_padding_mask.bool()[:, None, None, :], float("-inf"))
     o = (a.softmax(-1) @ v).transpose(1, 2).reshape(B, Lq, E)
     return F.linear(o, out_w, out_b)
 
@@ -72,10 +75,11 @@ class AttentionPoolOracle(nn.Module):
         self.attn = _MHAParams(embed_dim)
         self.norm = nn.LayerNorm(embed_dim)
 
-    def forward(self, x):
+    def forward(self, x, mask=None):
+        """mask: bool [B, N], True = ignored (models/attention_pool.py:61-101)."""
         q = self.query.expand(x.shape[0], -1, -1)
         o = mha_forward(q, x, self.attn.in_proj_weight, self.attn.in_proj_bias, self.attn.out_proj.weight,
-                        self.attn.out_proj.bias, self.num_heads)
+                        self.attn.out_proj.bias, self.num_heads, mask)
         return self.norm(o).squeeze(1)
 
 
@@ -108,11 +112,13 @@ class AttentionPoolWithCLSOracle(nn.Module):
         self.transformer = _EncStack(num_layers, embed_dim, 2048)
         self.norm = nn.LayerNorm(embed_dim)
 
-    def forward(self, x):
+    def forward(self, x, mask=None):
         x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1)
+        if mask is not None:  # the CLS token is never masked (models/attention_pool.py:180-184)
+            mask = torch.cat([torch.zeros(x.shape[0], 1, dtype=torch.bool), mask.bool()], dim=1)
         for l in self.transformer.layers:
             a = l.self_attn
-            x = l.norm1(x + mha_forward(x, x, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, self.num_heads))
+            x = l.norm1(x + mha_forward(x, x, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, self.num_heads, mask))
             x = l.norm2(x + l.linear2(F.relu(l.linear1(x))))
         return self.norm(x[:, 0])
 
@@ -126,10 +132,10 @@ class _AggBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = nn.Sequential(nn.Linear(dim, 4 * dim), nn.GELU(), nn.Dropout(0.0), nn.Linear(4 * dim, dim))
 
-    def forward(self, x):
+    def forward(self, x, key_padding_mask=None):
         h = self.norm1(x)
         x = x + mha_forward(h, h, self.attn.in_proj_weight, self.attn.in_proj_bias, self.attn.out_proj.weight,
-                            self.attn.out_proj.bias, self.heads)
+                            self.attn.out_proj.bias, self.heads, key_padding_mask)
         return x + self.mlp(self.norm2(x))
 
 
@@ -141,13 +147,21 @@ class AggregatorOracle(nn.Module):
         self.final_ln = nn.LayerNorm(dim)
         self.attn_query = nn.Parameter(torch.zeros(1, 1, dim))
 
-    def forward(self, x):
+    def forward(self, x, mask=None):
+        """mask: bool [B, N], True = padded video (models/video_aggregator.py:105-159, the masked variant included)."""
         B, N, D = x.shape
         x = x + self.pos_encoding[:, :N]
         for b in self.blocks:
-            x = b(x)
+            x = b(x, mask)
         x = self.final_ln(x)
-        w = torch.matmul(self.attn_query.expand(B, -1, -1), x.transpose(1, 2)).softmax(-1)
+        s = torch.matmul(self.attn_query.expand(B, -1, -1), x.transpose(1, 2))
+        if mask is not None:
+            mask = mask.bool()
+            x = x.masked_fill(mask.unsqueeze(-1), 0.0)
+            w = torch.nan_to_num(s.masked_fill(mask.unsqueeze(1), float("-inf")).softmax(-1), nan=0.0, posinf=0.0, neginf=0.0)
+            # rows without a valid video: uniform over the valid ones = all zero (:142-152)
+        else:
+            w = s.softmax(-1)
         return torch.bmm(w, x).squeeze(1)
 
 

@@ -239,6 +239,61 @@ def mil():
     np.savez_compressed(os.path.join(OUT, "mil.npz"), **out)
 
 
+MIL_VIEW_CASES = [  # view-angle embeddings (num_view_classes = 4; id 4 = PAD), 3-D and 4-D inputs
+    ("view_mean", dict(pooling_mode="mean", num_view_classes=4), False),
+    ("view_attention", dict(pooling_mode="attention", num_view_classes=4), False),
+    ("view_cls4d", dict(pooling_mode="cls_token", num_view_classes=4), True),
+    ("view_attention4d", dict(pooling_mode="attention", num_view_classes=4), True),
+    ("view_mean4d", dict(pooling_mode="mean", num_view_classes=4), True),
+]
+
+
+def mil_view():
+    """models/multi_instance_linear_probing.py:142-145,265-269: the view-angle embedding add in front of every pooling rule."""
+    M = load_by_path("ref_mil", "models/multi_instance_linear_probing.py")
+    g0 = np.load(os.path.join(OUT, "mil.npz"))
+    x3, x4, mask = torch.from_numpy(g0["x3"]), torch.from_numpy(g0["x4"]), torch.from_numpy(g0["mask"])
+    view_ids = torch.tensor([[0, 1, 2, 3, 4], [4, 4, 1, 0, 2], [3, 4, 4, 4, 4]], dtype=torch.long)
+    out = {"view_ids": np_(view_ids)}
+    import warnings
+    for name, kw, four in MIL_VIEW_CASES:
+        m = init_by_name(M.MultiInstanceLinearProbing(512, {"a": 3, "b": 1}, **kw)).eval()
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y = m(x4 if four else x3, mask=mask, view_ids=view_ids)
+        out[f"{name}_a"], out[f"{name}_b"] = np_(y["a"]), np_(y["b"])
+        out[f"{name}_keys"] = np.array(sorted(m.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "mil_view.npz"), **out)
+
+
+def pools_masked():
+    """key_padding_mask variants (True = ignored): models/attention_pool.py:61-101 (AttentionPool), :162-197
+    (AttentionPoolWithCLS, mask extended by an unmasked CLS column) and the masked EnhancedVideoAggregator
+    (models/video_aggregator.py:105-159) incl. a study with a single valid video."""
+    AP = load_by_path("ref_attention_pool", "models/attention_pool.py")
+    AG = load_by_path("ref_video_aggregator", "models/video_aggregator.py")
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 50, 512, generator=g)
+    mask = torch.zeros(3, 50, dtype=torch.bool)
+    mask[0, 30:] = True
+    mask[1, ::3] = True
+    mask[2, 1:] = True   # one valid token
+    ap = init_by_name(AP.AttentionPool(512, num_heads=8, dropout=0.0)).eval()
+    apc = init_by_name(AP.AttentionPoolWithCLS(512, num_heads=8, num_layers=1, dropout=0.0)).eval()
+    with torch.no_grad():
+        out.update(x=np_(x), mask=np_(mask), ap_y=np_(ap(x, mask=mask)), apcls_y=np_(apc(x, mask=mask)))
+    ag = init_by_name(AG.EnhancedVideoAggregator(512, num_heads=4, dropout=0.0, aggregator_depth=2)).eval()
+    for n in (4, 8):
+        xn = torch.randn(3, n, 512, generator=g)
+        mn = torch.zeros(3, n, dtype=torch.bool)
+        mn[0, n // 2:] = True
+        mn[2, 1:] = True
+        with torch.no_grad():
+            out[f"ag_x{n}"], out[f"ag_m{n}"], out[f"ag_y{n}"] = np_(xn), np_(mn), np_(ag(xn, mask=mn))
+    np.savez_compressed(os.path.join(OUT, "pools_masked.npz"), **out)
+
+
 def loss_zoo():
     """Remaining loss zoo: auto-balance / entropy-regularised contrastive.SigLIPLoss,
     siglip_pairwise.SiglipPairwiseFeatureLoss, multi_positive_infonce.MultiPositiveInfoNCELoss, and the runner's
@@ -316,7 +371,7 @@ def loss_zoo():
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (losses, rope, pools, bert, retrieval, loss_zoo, pools2, mil):
+    for fn in (losses, rope, pools, bert, retrieval, loss_zoo, pools2, mil, mil_view, pools_masked):
         if only and fn.__name__ not in only:
             continue
         fn()

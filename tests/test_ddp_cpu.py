@@ -44,10 +44,16 @@ def _ddp_worker(rank, world, port, bucket_mb, q):
         for p, r in zip(m.parameters(), ref.parameters()):
             assert torch.equal(p, r), "parameters were not broadcast from rank 0"
         nb = len(w._buckets)
-        for it in range(2):  # second iteration re-attaches / re-zeroes the arena
+        nparams = len(list(m.parameters()))
+        calls = []
+        for it in range(4):  # later iterations re-attach / re-zero the arena; from the second on: one hook per bucket
+            if it == 3:      # the trainable set changes (update_freeze_ratio): the wrapper learns the order again
+                m[0].weight.requires_grad_(False)
             w.attach_grads()
             x, y = _data(rank)
+            c0 = w.hook_calls
             ((w(x) - y) ** 2).mean().backward()
+            calls.append(w.hook_calls - c0)
             w.finish()
             # expected: mean over ranks of the per-rank gradient
             exp = [torch.zeros_like(p) for p in ref.parameters()]
@@ -58,8 +64,12 @@ def _ddp_worker(rank, world, port, bucket_mb, q):
                 for e, p in zip(exp, ref.parameters()):
                     e += p.grad / world
             for p, e in zip(m.parameters(), exp):
+                if not p.requires_grad:
+                    continue
                 assert p.grad.data_ptr() >= w._arena.data_ptr()  # a view into the flat arena
                 assert torch.allclose(p.grad, e, atol=1e-6), (it, (p.grad - e).abs().max())
+        # host cost: per-parameter hooks only while the arrival order is being learned
+        assert calls[0] == nparams and calls[1] == nb and calls[2] == nb and calls[3] == nparams - 1, (calls, nparams, nb)
         q.put((rank, "ok", nb))
     except Exception as e:  # noqa: BLE001
         q.put((rank, f"{type(e).__name__}: {e}", 0))
@@ -265,3 +275,41 @@ def test_run_epoch_val_collectives_world2():
     res = _run(_val_epoch_worker)
     assert [r[1] for r in res] == ["ok", "ok"], res
     assert res[0][2] == res[1][2], "every rank must report the same metric keys"
+
+
+def _val_epoch_no_text_worker(rank, world, port, q):
+    """A validation epoch whose steps produce no text embeddings (and no tokenizer): nothing can be ranked, so the retrieval
+    keys must be ABSENT on every rank (they used to be reported — and checkpointed — as real 0.0), the text gather
+    still runs on every rank (a rank-local `dim() == 2` used to guard that collective), and the other metrics still reduce."""
+    try:
+        _init(rank, world, port)
+        import deepcoro_clip_amd.runner as R
+
+        class Cfg:
+            recall_k, ndcg_k = [1, 5], [5]
+            device, world_size, is_ref_device = "cpu", world, rank == 0
+            gradient_accumulation_steps, max_grad_norm, loss_name, scheduler_name, temperature = 1, 5.0, "contrastive", "", 0.07
+
+        enc = torch.nn.Linear(2, 2)
+        loader = [{"videos": torch.zeros(2 + rank, 1)} for _ in range(2)]
+        runner = R.VideoContrastiveLearningRunner(config=Cfg(), train_loader=None, val_loader=loader, video_encoder=enc,
+                                                  text_encoder=enc, optimizer=None, log_temp=torch.zeros(1), loss_fn=None)
+        runner._val_step = lambda videos, **kw: ({"loss": 2.0 + rank}, {"video_embeddings": torch.ones(videos.shape[0], 8),
+                                                                         "text_embeddings": torch.empty(0)})
+        runner._preprocess_inputs = lambda batch: ({"videos": batch["videos"]}, [])
+        out = runner._run_epoch("val", 0)
+        assert abs(out["val/loss"] - 2.5) < 1e-6, out
+        assert not any("Recall" in k or "MRR" in k or "NDCG" in k or "MAP" in k or "MedianRank" in k for k in out), out
+        q.put((rank, "ok", sorted(out)))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}", 0))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_run_epoch_val_without_texts_drops_retrieval_keys_world2():
+    res = _run(_val_epoch_no_text_worker)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    assert res[0][2] == res[1][2]

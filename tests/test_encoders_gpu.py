@@ -239,3 +239,54 @@ def test_attention_pool_with_cls_matches_reference_golden():
     m = m.cuda().eval()
     y = m(torch.from_numpy(g["apcls_x"]).cuda())
     assert _rel(y.cpu(), torch.from_numpy(g["apcls_y"])) < 2e-4
+
+
+def test_masked_pools_and_aggregator_match_reference_golden_and_oracle_gradients():
+    """key_padding_mask (True = ignored) on the HIP path: AttentionPool, AttentionPoolWithCLS and the masked
+    EnhancedVideoAggregator against goldens produced by the reference modules (tests/golden/pools_masked.npz: ragged masks,
+    a row with a single valid token / video), and every gradient against the fp64 oracle."""
+    import os
+
+    import numpy as np
+    from deepcoro_clip_amd.attention_pool import AttentionPool, AttentionPoolWithCLS
+    from deepcoro_clip_amd.video_aggregator import EnhancedVideoAggregator
+    from oracle.model import AggregatorOracle, AttentionPoolOracle, AttentionPoolWithCLSOracle, init_by_name
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pools_masked.npz"))
+
+    def check(prod, orc, x, mask, ref, tol):
+        prod.load_state_dict({k: v.float() for k, v in orc.state_dict().items()})
+        prod = prod.cuda().eval()
+        xg = x.cuda().requires_grad_(True)
+        y = prod(xg, mask=mask.cuda())
+        assert _rel(y.detach().cpu(), ref) < tol, (type(prod).__name__, _rel(y.detach().cpu(), ref))
+        up = torch.randn(y.shape, generator=torch.Generator().manual_seed(3))
+        y.backward(up.cuda())
+        orc = orc.double()
+        xo = x.double().requires_grad_(True)
+        orc(xo, mask).backward(up.double())
+        relf = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm().clamp_min(1e-12))  # noqa: E731
+        assert relf(xg.grad, xo.grad) < 2e-3, (type(prod).__name__, relf(xg.grad, xo.grad))
+        # masked tokens / videos receive exactly no gradient
+        assert float(xg.grad.cpu()[mask].abs().max()) == 0.0
+        op = dict(orc.named_parameters())
+        norms = sorted(float(q.grad.norm()) for q in op.values() if q.grad is not None)
+        floor = 1e-3 * norms[len(norms) // 2]
+        for n, p in prod.named_parameters():
+            if op[n].grad is None:
+                continue
+            err = float((p.grad.detach().cpu().double() - op[n].grad).norm() / op[n].grad.norm().clamp_min(floor))
+            assert err < 3e-3, (type(prod).__name__, n, err)
+
+    x, mask = torch.from_numpy(g["x"]), torch.from_numpy(g["mask"])
+    check(AttentionPool(512, num_heads=8, dropout=0.0), init_by_name(AttentionPoolOracle(512, 8)), x, mask, torch.from_numpy(g["ap_y"]), 2e-4)
+    check(AttentionPoolWithCLS(512, num_heads=8, dropout=0.0), init_by_name(AttentionPoolWithCLSOracle(512, 8)), x, mask,
+          torch.from_numpy(g["apcls_y"]), 3e-4)
+    for n in (4, 8):
+        check(EnhancedVideoAggregator(512, num_heads=4, dropout=0.0, aggregator_depth=2), init_by_name(AggregatorOracle(512, 4, 2)),
+              torch.from_numpy(g[f"ag_x{n}"]), torch.from_numpy(g[f"ag_m{n}"]), torch.from_numpy(g[f"ag_y{n}"]), 2e-4)
+    # a study without any valid video pools to zeros (reference: fallback weights valid / sum(valid) = 0)
+    agg = EnhancedVideoAggregator(512, num_heads=4, dropout=0.0).cuda().eval()
+    allm = torch.ones(2, 4, dtype=torch.bool); allm[0, 0] = False
+    y = agg(torch.randn(2, 4, 512).cuda(), mask=allm.cuda())
+    assert torch.all(y[1] == 0) and torch.isfinite(y).all() and y[0].abs().max() > 0

@@ -56,12 +56,27 @@ def _oracle_run(key, build, x, gseed=1, coherent=False):
     return _ORACLE_CACHE[key]
 
 
-def _check_grads(prod, ref_grads, tol, relpos_tol, rope=False, floor_frac=1e-3):
+def _param_class(n: str) -> str:
+    if "rel_pos" in n:
+        return "rel_pos"
+    if ".pool." in n:
+        return "pool_conv"
+    if "norm" in n or "final_ln" in n:
+        return "norm"
+    if n.endswith("bias"):
+        return "bias"
+    return "weight"
+
+
+def _check_grads(prod, ref_grads, tol, relpos_tol=None, rope=False, floor_frac=1e-3, label=""):
     """Relative Frobenius error per parameter tensor; the denominator is floored at `floor_frac` x the median gradient
-    norm (bf16 rounding noise on a tensor whose own gradient is tiny scales with the activations, not with it)."""
+    norm (bf16 rounding noise on a tensor whose own gradient is tiny scales with the activations, not with it).
+    `tol`: one bar, or a dict per parameter class (rel_pos / pool_conv / norm / bias / weight) — set to about twice the
+    worst error MEASURED for that class on an MI355X (the measured worst cases are printed on every run)."""
     norms = sorted(float(g.norm()) for g in ref_grads.values() if g is not None)
     median = norms[len(norms) // 2]
     bad = []
+    worst: dict = {}
     for n, p in prod.named_parameters():
         ref = ref_grads[n]
         if ref is None:
@@ -76,10 +91,18 @@ def _check_grads(prod, ref_grads, tol, relpos_tol, rope=False, floor_frac=1e-3):
             assert float(ref.norm()) < 1e-9 * median, (n, float(ref.norm()), median)
             assert float(got.norm()) < 0.1 * median, (n, float(got.norm()), median)
             continue
-        t = relpos_tol if "rel_pos" in n else tol
+        cls = _param_class(n)
+        if isinstance(tol, dict):
+            t = tol[cls]
+        else:
+            t = (relpos_tol if relpos_tol is not None else tol) if cls == "rel_pos" else tol
         err = ((got - ref).norm() / ref.norm().clamp_min(floor_frac * median)).item()
+        if err > worst.get(cls, ("", 0.0))[1]:
+            worst[cls] = (n, err)
         if not err < t:
             bad.append((n, round(err, 4)))
+    print(f"[grad check {label}] worst relative Frobenius error per class: "
+          + "; ".join(f"{c} {e:.3e} ({n})" for c, (n, e) in sorted(worst.items())))
     assert not bad, bad[:20]
 
 
@@ -109,7 +132,7 @@ def test_video_encoder_full_geometry_fwd_and_all_grads(case, dtype, tol, gtol):
     assert out.shape == ref.shape == (c["B"], 512) and out.dtype == torch.float32
     assert _rel(out.cpu(), ref) < tol, _rel(out.cpu(), ref)
     out.backward(g.float().cuda())
-    _check_grads(prod, ref_grads, gtol, gtol * 4, floor_frac=1e-3 if dtype == torch.float32 else 2e-2)
+    _check_grads(prod, ref_grads, gtol, gtol * 4, floor_frac=1e-3 if dtype == torch.float32 else 2e-2, label=f"{case} {dtype}")
 
 
 def test_video_encoder_fp8_gemms_vs_oracle():
@@ -167,7 +190,8 @@ def test_rope_token_output_with_gradients(T, S, N, dtype, tol, gtol):
     assert _rel(out.float().cpu(), ref) < tol, _rel(out.float().cpu(), ref)
     out.backward(g.to(out.dtype).cuda())
     # the aggregator is unused on this path: no gradients there on either side
-    _check_grads(prod, ref_grads, gtol, gtol * 4, rope=True, floor_frac=1e-3 if dtype == torch.float32 else 2e-2)
+    _check_grads(prod, ref_grads, gtol, gtol * 4, rope=True, floor_frac=1e-3 if dtype == torch.float32 else 2e-2,
+                 label=f"rope {T}x{S} N{N} {dtype}")
 
 
 def test_config4_geometry_32_frames_rope_tokens_bf16():

@@ -260,3 +260,18 @@ def test_collate_layouts_and_text_bucketing():
     assert [m_["is_abnormal"] for m_ in mp["text_metadata"]] == [False, False, True]
     assert mp["reports"] == ["prompt a", "prompt b", "raw2"]
     assert set(mp) == {"videos", "encoded_texts", "positive_mask", "positive_weights", "text_ids", "text_metadata", "paths", "reports"}
+
+
+def test_frame_index_selection_matches_reference_rule():
+    """utils/video.py:243-251: fewer frames than expected -> repeat the last one; more -> torch.linspace(0, t-1, n).long()."""
+    from deepcoro_clip_amd.video import frame_indices
+    from oracle.video import load_video_frames
+    import numpy as np
+
+    assert frame_indices(3, 5) == [0, 1, 2, 2, 2]
+    assert frame_indices(10, 4) == [0, 3, 6, 9]
+    assert frame_indices(33, 16) == torch.linspace(0, 32, 16).long().tolist()
+    # the oracle applies the same rule: frame k of the output is frame idx[k] of the input (no resize, no normalisation)
+    clip = (np.arange(7, dtype=np.uint8)[:, None, None, None] * np.ones((1, 2, 2, 3), np.uint8))
+    out = load_video_frames(clip, n_frames=4, resize=None, normalize=False)
+    assert out[:, 0, 0, 0].tolist() == [float(i) for i in frame_indices(7, 4)]

@@ -70,3 +70,76 @@ def test_text_length_bucketing_leaves_cls_embedding_unchanged():
         full = te(ids.cuda(), mask.cuda())
         short = te(tid.cuda(), tmask.cuda())
     assert (full - short).abs().max() < 2e-5 * full.abs().max().clamp_min(1.0)
+
+
+@pytest.mark.parametrize("shape,n_frames,resize,backbone", [
+    ((20, 97, 131, 3), 8, 56, "default"),     # temporal sub-sampling (linspace), non-square down-scaling
+    ((5, 64, 48, 3), 8, 112, "default"),      # last-frame padding, up-scaling
+    ((40, 300, 300), 32, 224, "mvit"),        # grayscale [F, H, W]; backbone 'mvit' forces 16 frames (utils/video.py:233-235)
+    ((16, 224, 224, 1), 16, 224, "default"),  # identity size, grayscale [F, H, W, 1]
+    ((16, 480, 640, 3), 16, 224, "default"),  # a realistic 640 x 480 source
+])
+def test_gpu_resize_normalise_matches_reference_pipeline(shape, n_frames, resize, backbone, tmp_path):
+    """dcc_resize_frames_u8 (frame select + anti-aliased bilinear resize + normalise, one kernel) against the CPU oracle of
+    utils/video.py:206-295, which executes the very ATen operator torchvision's v2.Resize calls.  fp32 output: within 2e-4
+    pixel units of the reference before normalisation (fp32 summation order only); uint8 output: never more than 1 LSB from the
+    rounded reference, and equal on > 99.9 % of the samples (a value within rounding noise of x.5 may round the other way)."""
+    import numpy as np
+
+    from deepcoro_clip_amd import video as V
+    from oracle.video import load_video_frames
+
+    rng = np.random.default_rng(7)
+    frames = rng.integers(0, 256, shape, dtype=np.uint8)
+    mean, std = [110.2, 101.5, 95.25], [60.0, 58.5, 62.25]
+    ref = load_video_frames(frames, n_frames, resize, True, mean, std, backbone)
+    path = str(tmp_path / "clip.npy")
+    np.save(path, frames)
+    got = V.load_video(path, n_frames=n_frames, resize=resize, normalize=True, mean=mean, std=std, backbone=backbone)
+    T = 16 if backbone == "mvit" else n_frames
+    assert got.shape == (T, resize, resize, 3) == ref.shape and got.dtype == torch.float32 and got.is_cuda
+    err = (got.cpu() - torch.from_numpy(ref)).abs().max().item()
+    assert err < 2e-4 / 58.5 * 1.5, err
+    raw = load_video_frames(frames, n_frames, resize, False, backbone=backbone)
+    got_raw = V.preprocess_frames(frames, n_frames, resize, normalize=False, backbone=backbone)
+    assert (got_raw.cpu() - torch.from_numpy(raw)).abs().max().item() < 2e-4
+    u8 = V.preprocess_frames(frames, n_frames, resize, backbone=backbone, out_uint8=True)
+    want = torch.from_numpy(raw).round().clamp(0, 255).to(torch.uint8)
+    d = (u8.cpu().int() - want.int()).abs()
+    assert u8.dtype == torch.uint8 and int(d.max()) <= 1 and float((d == 0).float().mean()) > 0.999
+
+
+def test_gpu_resized_uint8_clip_feeds_the_byte_patch_gather():
+    """The whole input side in bytes: native-size uint8 frames -> resize kernel (uint8 out) -> VideoEncoder's uint8 path
+    (normalisation inside dcc_im2col3d_u8) == the fp32 pipeline on the same rounded pixels."""
+    import numpy as np
+
+    from deepcoro_clip_amd import video as V
+    from deepcoro_clip_amd.video_encoder import VideoEncoder
+
+    rng = np.random.default_rng(9)
+    frames = rng.integers(0, 256, (9, 120, 90, 3), dtype=np.uint8)
+    mean, std = [110.2, 101.5, 95.25], [60.0, 58.5, 62.25]
+    clip8 = V.preprocess_frames(frames, n_frames=4, resize=64, out_uint8=True)
+    ve = VideoEncoder(num_frames=4, spatial_size=(64, 64), pretrained=False, freeze_ratio=1.0, dropout=0.0,
+                      compute_dtype=torch.float32, stochastic_depth_prob=0.0).cuda().eval()
+    ve.set_input_normalization(mean, std)
+    with torch.no_grad():
+        a = ve(clip8[None])
+        host = (clip8.float() - torch.tensor(mean, device="cuda")) / torch.tensor(std, device="cuda")
+        b = ve(host[None])
+    assert (a - b).abs().max().item() < 1e-4 * b.abs().max().item()
+
+
+def test_video_input_errors():
+    import numpy as np
+
+    from deepcoro_clip_amd import video as V
+
+    with pytest.raises(NotImplementedError):
+        V.load_video("clip.mp4")
+    with pytest.raises(TypeError):
+        V.preprocess_frames(np.zeros((4, 8, 8, 3), np.float32))
+    with pytest.raises(ValueError):
+        V.preprocess_frames(np.zeros((4, 8, 8, 2), np.uint8))
+    assert V.frame_indices(3, 5) == [0, 1, 2, 2, 2] and V.frame_indices(10, 4) == [0, 3, 6, 9] and V.frame_indices(4, 4) == [0, 1, 2, 3]

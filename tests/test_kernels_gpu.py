@@ -1,6 +1,7 @@
 """Bandwidth-bound HIP kernels (LayerNorm, depthwise/max pooling, patch embedding, RoPE, embeddings, token mean,
 elementwise) through the C ABI against plain PyTorch fp32 references of the same op, plus the reference-generated
 RoPE golden (tests/golden/rope.npz).  fp32: 1e-5-class; bf16: 1e-2-class (tolerances stated per test)."""
+import math
 import os
 
 import numpy as np
@@ -189,6 +190,33 @@ def test_k_pool_writes_the_one_hot_key_augmentation(stride, thw, H, B, A):
     dims = K.relpos_dims(B, H, C, A, 8, (1, 1, 1), k_thw, (1, 1, 1))   # only the key grid matters to kaug
     K.relpos_kaug(ref, dims)
     assert torch.equal(Kf, ref)
+
+
+def test_fused_k_pool_declines_augmentations_wider_than_64():
+    """k_t + k_h + k_w > 64 (e.g. 32 frames x 448^2 in block 1) needs a 96-wide one-hot key augmentation: outside the fused
+    kernel's domain, so dcc_pool_ln_fwd must answer DCC_ERR_UNSUPPORTED (wrapper: None -> the caller takes conv + LayerNorm +
+    relpos_kaug), not an argument error; an augmentation that is not a multiple of 32 stays an argument error."""
+    from deepcoro_clip_amd import kernels as K
+    from deepcoro_clip_amd._lib import DccError
+
+    C, A = 96, 96
+    g = _gen(23)
+    geo = K.PoolGeom(1, 2, C, (20, 28, 28), (3, 3, 3), (1, 1, 1), (1, 1, 1), True)
+    qkv = (torch.randn(1, geo.n_in, 3, 2, C, generator=g) * 0.7).bfloat16().cuda()
+    w = (torch.randn(C, 27, generator=g) * 0.2).cuda()
+    gam = (torch.rand(C, generator=g) + 0.5).cuda(); bet = (torch.randn(C, generator=g) * 0.1).cuda()
+    assert sum(geo.out_thw) > 64
+    Kf = torch.full((1, geo.n_out, 2, C + A), 7.0, device="cuda", dtype=torch.bfloat16)
+    assert K.pool_ln_fwd(qkv[:, :, 1], geo, w, gam, bet, 1e-6, Kf.view(-1, C + A)[:, :C], aug=A) is None
+    assert torch.all(Kf == 7.0)   # nothing was launched
+    # the unfused path the caller falls back to writes all 96 augmentation columns
+    conv, _ = K.pool_fwd(qkv[:, :, 1], geo, w)
+    K.layernorm_fwd(conv.view(-1, C), gam, bet, 1e-6, out=Kf.view(-1, C + A)[:, :C])
+    K.relpos_kaug(Kf, K.relpos_dims(1, 2, C, A, 8, (1, 1, 1), geo.out_thw, (1, 1, 1)))
+    aug = Kf[0, 1:, 0, C:].float()
+    assert torch.all(aug.sum(-1) == 3.0) and torch.all(Kf[0, 0, :, C:] == 0)   # one hot per axis; class token: none
+    with pytest.raises(DccError):
+        K.pool_ln_fwd(qkv[:, :, 1], geo, w, gam, bet, 1e-6, Kf.view(-1, C + A)[:, :C], aug=40)
 
 
 @pytest.mark.parametrize("stride,thw,H,B", [((1, 2, 2), (8, 14, 14), 4, 3), ((1, 8, 8), (8, 56, 56), 1, 2), ((1, 1, 1), (4, 7, 7), 8, 2)])
@@ -441,3 +469,35 @@ def test_u8_normalize_matches_host_normalisation_bit_exact():
     ref = (frames.float() - mean) / std
     out = K.u8_normalize(frames.cuda(), mean.cuda(), std.cuda())
     assert out.dtype == torch.float32 and torch.equal(out.cpu(), ref)
+
+
+def test_bf16_gelu_pair_against_erf():
+    """The bf16 GEMM epilogues evaluate GELU as x * sigmoid(x (1.6003 + 0.0694 x^2)) (csrc/common.h), the reference
+    (torchvision MViT MLP, HF BERT: nn.GELU) uses erf.  Bound the difference at kernel level over [-8, 8]:
+    forward through a GEMM epilogue (A = [x | 0], B = [1 | 0]: the product is x exactly), derivative through dcc_dgelu_mul."""
+    from deepcoro_clip_amd import kernels as K
+
+    M = 8192
+    x = torch.linspace(-8.0, 8.0, M).bfloat16()          # the bf16 grid points the kernel sees
+    a = torch.zeros(M, 32, dtype=torch.bfloat16); a[:, 0] = x
+    b = torch.zeros(128, 32, dtype=torch.bfloat16); b[:, 0] = 1.0
+    pre = torch.empty(M, 128, dtype=torch.bfloat16, device="cuda")
+    y = K.gemm(a.cuda(), b.cuda(), gelu=True, save_pre=True, aux=pre)
+    assert torch.equal(pre[:, 0].cpu(), x) and torch.equal(pre[:, 5].cpu(), x)
+    xd = x.double()
+    ref = 0.5 * xd * (1.0 + torch.erf(xd / math.sqrt(2.0)))
+    err = (y[:, 0].double().cpu() - ref).abs()
+    bound = 2.8e-4 + ref.abs() * 2.0 ** -8          # fit error + one bf16 rounding of the result
+    assert torch.all(err <= bound), (float(err.max()), float(xd[(err - bound).argmax()]))
+    # derivative: dy = 1 -> dgelu(pre)
+    d = K.dgelu_mul(torch.ones(M, device="cuda", dtype=torch.bfloat16), x.cuda())
+    dref = 0.5 * (1.0 + torch.erf(xd / math.sqrt(2.0))) + xd * torch.exp(-0.5 * xd * xd) / math.sqrt(2.0 * math.pi)
+    derr = (d.double().cpu() - dref).abs()
+    dbound = 9.0e-4 + dref.abs() * 2.0 ** -8
+    assert torch.all(derr <= dbound), (float(derr.max()), float(xd[(derr - dbound).argmax()]))
+    # forward / backward consistency: the kernel's derivative is the derivative of the kernel's forward (central difference
+    # of the closed form in fp64)
+    g = lambda t: t / (1.0 + torch.exp(-t * (1.60031417 + 0.06940178 * t * t)))  # noqa: E731
+    num = (g(xd + 1e-5) - g(xd - 1e-5)) / 2e-5
+    assert torch.all((d.double().cpu() - num).abs() <= 1e-5 + num.abs() * 2.0 ** -8)
+    print(f"[gelu] max |gelu_bf16 - erf form| {float(err.max()):.2e}, max |dgelu_bf16 - erf form| {float(derr.max()):.2e}")

@@ -57,6 +57,48 @@ def test_mil_matches_reference_golden_and_oracle_gradients(idx):
         assert p.grad is not None and err < 2e-3, (name, n, err)
 
 
+@pytest.mark.parametrize("idx", range(5))
+def test_mil_view_angle_embeddings_match_reference_golden_and_oracle_gradients(idx):
+    """num_view_classes > 0 (models/multi_instance_linear_probing.py:142-145,265-269): x + view_embedding(view_ids) broadcast
+    over the patch axis, in front of every pooling rule — outputs against goldens produced by the reference module
+    (tests/golden/mil_view.npz), gradients (input, embedding table, everything else) against the fp64 oracle."""
+    from deepcoro_clip_amd.multi_instance_linear_probing import MultiInstanceLinearProbing
+    from oracle.mil import MILOracle
+    from oracle.model import init_by_name
+    from tests.golden.make_golden import MIL_VIEW_CASES
+
+    name, kw, four = MIL_VIEW_CASES[idx]
+    g0 = np.load(os.path.join(G, "mil.npz"))
+    g = np.load(os.path.join(G, "mil_view.npz"))
+    x = torch.from_numpy(g0["x4"] if four else g0["x3"])
+    mask, vid = torch.from_numpy(g0["mask"]), torch.from_numpy(g["view_ids"])
+    orc = init_by_name(MILOracle(512, {"a": 3, "b": 1}, mode=kw["pooling_mode"], num_view_classes=kw["num_view_classes"])).double()
+    m = MultiInstanceLinearProbing(512, {"a": 3, "b": 1}, **kw)
+    assert sorted(m.state_dict().keys()) == list(g[f"{name}_keys"]) and m.view_pad_id == 4
+    m.load_state_dict({k: v.float() for k, v in orc.state_dict().items()})
+    m = m.cuda().eval()
+    xg = x.cuda().requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = m(xg, mask=mask.cuda(), view_ids=vid.cuda())
+    for h in ("a", "b"):
+        ref = torch.from_numpy(g[f"{name}_{h}"])
+        assert (y[h].float().cpu() - ref).abs().max() < 2e-4 * ref.abs().max().clamp_min(1.0), (name, h)
+    xo = x.double().requires_grad_(True)
+    yo = orc(xo, mask, vid)
+    (yo["a"].sum() + 2.0 * yo["b"].sum()).backward()
+    (y["a"].sum() + 2.0 * y["b"].sum()).backward()
+    rel = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm().clamp_min(1e-9))  # noqa: E731
+    assert rel(xg.grad, xo.grad) < 1e-3, (name, rel(xg.grad, xo.grad))
+    assert rel(m.view_embedding.weight.grad, orc.view_embedding.weight.grad) < 2e-3, name
+    with pytest.raises(IndexError):
+        m(xg.detach(), mask=mask.cuda(), view_ids=torch.full_like(vid, 5).cuda())
+    # view ids without view classes configured are ignored, like the reference (:265)
+    m0 = MultiInstanceLinearProbing(512, {"a": 3}, pooling_mode="mean").cuda().eval()
+    x3 = torch.from_numpy(g0["x3"]).cuda()
+    assert torch.equal(m0(x3, view_ids=vid.cuda())["a"], m0(x3)["a"])
+
+
 def test_mil_edge_cases_and_errors():
     from deepcoro_clip_amd.multi_instance_linear_probing import MultiInstanceLinearProbing
 

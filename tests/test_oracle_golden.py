@@ -267,3 +267,44 @@ def test_mil_oracle_matches_reference():
             y = m(x4 if four else x3, mask)
         for h in ("a", "b"):
             assert (y[h] - torch.from_numpy(g[f"{name}_{h}"])).abs().max() < 2e-5, (name, h)
+
+
+def test_mil_view_embedding_oracle_matches_reference():
+    """tests/golden/mil_view.npz: the view-angle embedding add (models/multi_instance_linear_probing.py:142-145,265-269) in
+    front of the pooling rules, 3-D and hierarchical 4-D inputs, PAD ids included."""
+    import os
+
+    import numpy as np
+    from oracle.mil import MILOracle
+    from oracle.model import init_by_name
+    from tests.golden.make_golden import MIL_VIEW_CASES
+
+    g0 = np.load(os.path.join(os.path.dirname(__file__), "golden", "mil.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mil_view.npz"))
+    x3, x4, mask = torch.from_numpy(g0["x3"]), torch.from_numpy(g0["x4"]), torch.from_numpy(g0["mask"])
+    vid = torch.from_numpy(g["view_ids"])
+    for name, kw, four in MIL_VIEW_CASES:
+        m = init_by_name(MILOracle(512, {"a": 3, "b": 1}, mode=kw["pooling_mode"], num_view_classes=kw["num_view_classes"])).eval()
+        assert sorted(m.state_dict().keys()) == list(g[f"{name}_keys"]), name
+        with torch.no_grad():
+            y = m(x4 if four else x3, mask, vid)
+        for h in ("a", "b"):
+            assert (y[h] - torch.from_numpy(g[f"{name}_{h}"])).abs().max() < 2e-5, (name, h)
+
+
+def test_masked_pools_oracle_matches_reference():
+    """tests/golden/pools_masked.npz: key_padding_mask variants of AttentionPool / AttentionPoolWithCLS
+    (models/attention_pool.py:61-101,162-197) and the masked EnhancedVideoAggregator (models/video_aggregator.py:105-159)."""
+    from oracle.model import AggregatorOracle, AttentionPoolOracle, AttentionPoolWithCLSOracle, init_by_name
+
+    g = _load("pools_masked.npz")
+    x, mask = _t(g["x"]), torch.from_numpy(g["mask"])
+    with torch.no_grad():
+        ap = init_by_name(AttentionPoolOracle(512, 8))
+        assert np.allclose(ap(x, mask).numpy(), g["ap_y"], atol=2e-5)
+        apc = init_by_name(AttentionPoolWithCLSOracle(512, 8)).eval()
+        assert np.allclose(apc(x, mask).numpy(), g["apcls_y"], atol=5e-5)
+        ag = init_by_name(AggregatorOracle(512, 4, 2))
+        for n in (4, 8):
+            y = ag(_t(g[f"ag_x{n}"]), torch.from_numpy(g[f"ag_m{n}"]))
+            assert np.allclose(y.numpy(), g[f"ag_y{n}"], atol=2e-5), n
