@@ -396,6 +396,45 @@ __global__ void fp8_quant_kernel(const T* __restrict__ x, int64_t rows, int64_t 
     out[r * ldo4 + c / 4] = pack4_fp8(to_f32(p[0]) * mul, to_f32(p[1]) * mul, to_f32(p[2]) * mul, to_f32(p[3]) * mul, fmax_, bf8);
   }
 }
+// Contiguous bf16 activations (the case every layer hits: ldx == cols, 16-byte aligned, n % 8 == 0): 16-byte loads, no index
+// arithmetic — the generic kernels above spend a 64-bit division per ELEMENT and ran at 0.3 TB/s (tools/gemm_bench.py, r03:
+// 375 us to quantise a [50 208, 384] activation, three times its GEMM); these stream at HBM rate.
+__global__ __launch_bounds__(256) void absmax_bf16_flat_kernel(const uint4* __restrict__ x, int64_t n8, float* __restrict__ amax) {
+  unsigned m = 0;   // max over |x| as bf16 bit patterns (sign cleared): orders like the values
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const uint4 v = x[i];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned lo = w[e] & 0x7fffu, hi = (w[e] >> 16) & 0x7fffu;
+      m = max(m, lo > 0x7f80u ? 0u : lo);   // NaN patterns are skipped, like fmaxf does in the generic kernel
+      m = max(m, hi > 0x7f80u ? 0u : hi);
+    }
+  }
+  float f = wave_max(__uint_as_float(m << 16));
+  if ((threadIdx.x & 63) == 0 && f > 0.0f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(f));
+}
+__global__ __launch_bounds__(256) void fp8_quant_bf16_flat_kernel(const uint4* __restrict__ x, int64_t n8, const float* __restrict__ amax,
+                                                                  uint2* __restrict__ out, float fmax_, int bf8,
+                                                                  float* __restrict__ scale_out) {
+  const float am = *amax;
+  const float mul = am > 0.0f ? fmax_ / am : 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = am > 0.0f ? am / fmax_ : 1.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const uint4 v = x[i];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[2 * e] = __uint_as_float(w[e] << 16) * mul;
+      f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u) * mul;
+    }
+    uint2 o;
+    o.x = pack4_fp8(f[0], f[1], f[2], f[3], fmax_, bf8);
+    o.y = pack4_fp8(f[4], f[5], f[6], f[7], fmax_, bf8);
+    out[i] = o;
+  }
+}
 // transposed output: out8[c][r] = fp8(x[r][c] * mul): 32 x 32 tiles through LDS (weights only: small)
 template <typename T>
 __global__ __launch_bounds__(256) void fp8_quant_t_kernel(const T* __restrict__ x, int rows, int cols, int64_t ldx,
@@ -435,6 +474,11 @@ extern "C" int dcc_relu(const void* x, const void* gate, void* y, int64_t n, int
 }
 extern "C" int dcc_absmax(const void* x, int64_t rows, int64_t cols, int64_t ldx, int dtype, float* amax, void* stream) {
   if (!x || !amax || rows <= 0 || cols <= 0) return DCC_ERR_ARG;
+  if (dtype == DCC_BF16 && ldx == cols && ((rows * cols) % 8) == 0 && !((uintptr_t)x & 15)) {
+    const int64_t n8 = rows * cols / 8;
+    hipLaunchKernelGGL(absmax_bf16_flat_kernel, dim3(gs_blocks(n8, 2)), dim3(256), 0, ST, (const uint4*)x, n8, amax);
+    return dcc_check_launch();
+  }
   dim3 g(gs_blocks(rows * cols, 8));
   if (dtype == DCC_BF16) hipLaunchKernelGGL((absmax_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, rows, cols, ldx, amax);
   else if (dtype == DCC_F32) hipLaunchKernelGGL((absmax_kernel<float>), g, dim3(256), 0, ST, (const float*)x, rows, cols, ldx, amax);
@@ -455,6 +499,12 @@ extern "C" int dcc_fp8_quantize(const void* x, int64_t rows, int64_t cols, int64
     return dcc_check_launch();
   }
   if ((cols % 4) || (ldo % 4) || ((uintptr_t)out8 & 3)) return DCC_ERR_UNSUPPORTED;
+  if (dtype == DCC_BF16 && ldx == cols && ldo == cols && ((rows * cols) % 8) == 0 && !((uintptr_t)x & 15) && !((uintptr_t)out8 & 7)) {
+    const int64_t n8 = rows * cols / 8;
+    hipLaunchKernelGGL(fp8_quant_bf16_flat_kernel, dim3(gs_blocks(n8, 2)), dim3(256), 0, ST, (const uint4*)x, n8, amax, (uint2*)out8, fmax_,
+                       fmt, scale_out);
+    return dcc_check_launch();
+  }
   dim3 g(gs_blocks(rows * cols / 4, 4));
   if (dtype == DCC_BF16) hipLaunchKernelGGL((fp8_quant_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, rows, cols, ldx, amax, (unsigned*)out8, ldo / 4, fmax_, fmt, scale_out);
   else if (dtype == DCC_F32) hipLaunchKernelGGL((fp8_quant_kernel<float>), g, dim3(256), 0, ST, (const float*)x, rows, cols, ldx, amax, (unsigned*)out8, ldo / 4, fmax_, fmt, scale_out);

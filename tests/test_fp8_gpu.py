@@ -32,6 +32,10 @@ def test_fp8_quantize_matches_torch_float8(fmt, dtype):
     qt, st = K.fp8_quantize(x[:, :128].contiguous(), fmt, transpose=True)
     q2, _ = K.fp8_quantize(x[:, :128].contiguous(), fmt)
     assert qt.shape == (128, 300) and torch.equal(qt.t().contiguous(), q2)
+    # a strided view takes the generic kernels, a contiguous bf16 tensor the 16-byte streaming ones: identical bytes
+    qs, ss = K.fp8_quantize(x[:, 64:192], fmt)
+    qc, sc = K.fp8_quantize(x[:, 64:192].contiguous(), fmt)
+    assert torch.equal(qs, qc) and torch.equal(ss, sc)
     z, sz = K.fp8_quantize(torch.zeros(8, 16, device="cuda", dtype=dtype), fmt)
     assert sz.item() == 1.0 and int(z.max()) == 0
 

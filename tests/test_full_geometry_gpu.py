@@ -106,6 +106,14 @@ def _check_grads(prod, ref_grads, tol, relpos_tol=None, rope=False, floor_frac=1
     assert not bad, bad[:20]
 
 
+# Gradient bars per parameter class = about twice the worst relative Frobenius error MEASURED on an MI355X (r03 run, printed by
+# every run as "[grad check ...]"): fp32 worst cases 5.5e-5 (bias) ... 2.0e-3 (rel_pos: sums of ~1e5 incoherent terms against the
+# fp64 oracle); bf16 at 16 x 224^2: bias 1.7e-2, norm 8.3e-2, pool_conv 8.2e-2, rel_pos 1.15e-1, weight 8.4e-2; the 4 x 64^2 RoPE case
+# is noisier (few tokens per table entry): bias 7.7e-2, norm 1.8e-1, pool_conv 1.25e-1, rel_pos 1.95e-1, weight 1.4e-1.
+GTOL_F32 = {"bias": 2e-4, "norm": 2.5e-3, "pool_conv": 3e-3, "rel_pos": 4e-3, "weight": 2.6e-3}
+GTOL_BF16 = {"bias": 4e-2, "norm": 1.6e-1, "pool_conv": 1.6e-1, "rel_pos": 2.2e-1, "weight": 1.6e-1}
+GTOL_BF16_TINY = {"bias": 1.5e-1, "norm": 3.4e-1, "pool_conv": 2.5e-1, "rel_pos": 3.8e-1, "weight": 2.7e-1}
+
 CASES = {
     # key: (T, S, B, N, pooling, oracle kwargs / product kwargs)
     "c1_single": dict(T=16, S=224, B=2, N=0, pooling="mean"),
@@ -113,7 +121,7 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 3e-3), (torch.bfloat16, 5e-2, 2e-1)])
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, GTOL_F32), (torch.bfloat16, 5e-2, GTOL_BF16)])
 @pytest.mark.parametrize("case", list(CASES))
 def test_video_encoder_full_geometry_fwd_and_all_grads(case, dtype, tol, gtol):
     """configs[1] (single video) and configs[2] (N = 4 videos per study, AttentionPool + aggregator) at 16 x 224 x 224."""
@@ -132,7 +140,7 @@ def test_video_encoder_full_geometry_fwd_and_all_grads(case, dtype, tol, gtol):
     assert out.shape == ref.shape == (c["B"], 512) and out.dtype == torch.float32
     assert _rel(out.cpu(), ref) < tol, _rel(out.cpu(), ref)
     out.backward(g.float().cuda())
-    _check_grads(prod, ref_grads, gtol, gtol * 4, floor_frac=1e-3 if dtype == torch.float32 else 2e-2, label=f"{case} {dtype}")
+    _check_grads(prod, ref_grads, gtol, floor_frac=1e-3 if dtype == torch.float32 else 2e-2, label=f"{case} {dtype}")
 
 
 def test_video_encoder_fp8_gemms_vs_oracle():
@@ -169,7 +177,7 @@ def test_video_encoder_fp8_gemms_vs_oracle():
     assert outs["bf16"][0] < 5e-2 and outs["bf16"][1] > 0.995, outs
 
 
-@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 3e-3), (torch.bfloat16, 5e-2, 2e-1)])
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, GTOL_F32), (torch.bfloat16, 5e-2, GTOL_BF16)])
 @pytest.mark.parametrize("T,S,N", [(4, 64, 2), (16, 224, 1)])
 def test_rope_token_output_with_gradients(T, S, N, dtype, tol, gtol):
     """use_rope=True, per_video_pool=False (all patch tokens), forward AND gradients: the rotation after pooling, its
@@ -190,7 +198,9 @@ def test_rope_token_output_with_gradients(T, S, N, dtype, tol, gtol):
     assert _rel(out.float().cpu(), ref) < tol, _rel(out.float().cpu(), ref)
     out.backward(g.to(out.dtype).cuda())
     # the aggregator is unused on this path: no gradients there on either side
-    _check_grads(prod, ref_grads, gtol, gtol * 4, rope=True, floor_frac=1e-3 if dtype == torch.float32 else 2e-2,
+    if dtype == torch.bfloat16 and S < 224:
+        gtol = GTOL_BF16_TINY
+    _check_grads(prod, ref_grads, gtol, rope=True, floor_frac=1e-3 if dtype == torch.float32 else 2e-2,
                  label=f"rope {T}x{S} N{N} {dtype}")
 
 

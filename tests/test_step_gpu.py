@@ -108,7 +108,7 @@ def test_train_step_loss_curve_vs_oracle(dtype, steps, tol):
     lt, opt = _oracle_trainer(vo, to, 0.07)
     all_params = list(vo.parameters()) + list(to.parameters())
     g = torch.Generator().manual_seed(99)
-    worst = 0.0
+    worst, n_decided, cos_dev = 0.0, 0, 0.0
     for step in range(steps):
         videos = torch.randn(B, 4, 64, 64, 3, generator=g)
         ids = torch.randint(0, 512, (B, 16), generator=g)
@@ -136,23 +136,29 @@ def test_train_step_loss_curve_vs_oracle(dtype, steps, tol):
             assert abs(m["alignment_cosine"] - ref_m["alignment_cosine"]) < mt
             assert abs(m["alignment_score"] - ref_m["alignment_score"]) < mt
             assert emb["video_embeddings"].shape == (B, 512) and emb["video_embeddings"].dtype == torch.float32
+            if dtype == torch.float32:
+                sim = torch.nn.functional.normalize(emb["video_embeddings"], dim=1) @ torch.nn.functional.normalize(emb["text_embeddings"], dim=1).t()
+                sim_ref = torch.nn.functional.normalize(v.detach(), dim=1) @ torch.nn.functional.normalize(t.detach(), dim=1).t()
+                assert torch.equal(sim.argmax(1).cpu(), sim_ref.argmax(1))
+        if dtype == torch.bfloat16:
+            # north_star: embedding argmax bit-exact.  In bf16 a row whose best and second-best cosine are closer than bf16's
+            # own noise on a cosine (1e-2 class; measured max |cosine - oracle| 1.9e-3 at step 0) has no defined argmax;
+            # every row with a clear winner must agree, at every step of the curve (the embeddings separate as training goes on)
             sim = torch.nn.functional.normalize(emb["video_embeddings"], dim=1) @ torch.nn.functional.normalize(emb["text_embeddings"], dim=1).t()
             sim_ref = torch.nn.functional.normalize(v.detach(), dim=1) @ torch.nn.functional.normalize(t.detach(), dim=1).t()
-            if dtype == torch.float32:
-                assert torch.equal(sim.argmax(1).cpu(), sim_ref.argmax(1))
-            else:
-                # bf16: north_star asks for bit-exact embedding argmax; a row whose best and second-best similarities are
-                # closer than bf16's own noise on a cosine (8 mantissa bits through a 16-block trunk: measured < 2e-2 here)
-                # has no defined argmax in bf16, every other row must agree exactly
-                top2 = sim_ref.topk(2, dim=1).values
-                decided = (top2[:, 0] - top2[:, 1]) > 4e-2
-                assert torch.equal(sim.argmax(1).cpu()[decided], sim_ref.argmax(1)[decided]), (sim.cpu(), sim_ref)
-                print(f"[loss-curve] bf16 argmax: {int(decided.sum())}/{B} rows with a margin above bf16 noise, all equal; "
-                      f"max |cosine - oracle| {float((sim.cpu() - sim_ref).abs().max()):.2e}")
+            top2 = sim_ref.topk(2, dim=1).values
+            decided = (top2[:, 0] - top2[:, 1]) > 1e-2
+            assert torch.equal(sim.argmax(1).cpu()[decided], sim_ref.argmax(1)[decided]), (step, sim.cpu(), sim_ref)
+            n_decided += int(decided.sum())
+            cos_dev = max(cos_dev, float((sim.cpu() - sim_ref).abs().max()))
     # parameters stay together too (fp32): temperature after `steps` updates
     if dtype == torch.float32:
         assert abs(runner.log_temp.item() - lt.item()) < 1e-5
     print(f"[loss-curve] {dtype} worst relative deviation over {steps} steps: {worst:.2e}")
+    if dtype == torch.bfloat16:
+        print(f"[loss-curve] bf16 argmax: {n_decided}/{B * steps} rows with a margin above 1e-2, all equal to the oracle's; "
+              f"max |cosine - oracle| over the curve {cos_dev:.2e}")
+
 
 
 def test_gradient_accumulation_and_val_step():
