@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void pool_bwd_data_kernel(const TD* __restrict
 // frame -> 9 independent 16-byte loads in flight per thread and 72 fp32 accumulators, so 4+ blocks fit per CU
 // (the first version kept 27x4 accumulators per thread, one block per CU, and was latency-bound).
 // Thread = (slot, chunk): slot % 3 = kt stays fixed over the grid-stride loop (the stride is a multiple of 3),
-// so the per-thread sums fold into LDS red[27][C] once, then the block's partial goes to the workspace.
+// so the per-thread sums fold into LDS red[27][C] once, then the block's partial is added into dw.
 template <typename T, typename TD>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const TD* __restrict__ dy, const T* __restrict__ x,
                                                                 float* __restrict__ ws, PoolGeom g) {
@@ -459,42 +459,12 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const TD* __rest
       }
   }
   __syncthreads();
-  // per-block partial -> workspace (plain coalesced stores); dwconv_reduce_kernel folds the blocks.
-  float* part = ws + (int64_t)blockIdx.x * taps * g.C;
-  for (int i = threadIdx.x; i < taps * g.C; i += blockDim.x) part[i] = red[i];
-}
-
-// dw[c][tap] += sum_b ws[b][tap][c]; block = 32 outputs x 8 interleaved block-groups (coalesced 128-byte rows,
-// 8 loads in flight per thread), folded through LDS; the partials are split over gridDim.y slices (one slice would
-// walk them in latency-bound rounds of 64) and each slice adds its sum with one atomic per output.
-__global__ __launch_bounds__(256) void dwconv_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                            int nblocks, int taps, int C) {
-  __shared__ float part[8][33];
-  const int il = threadIdx.x & 31, bg = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + il;
-  const int n = taps * C;
-  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
-  float acc = 0.0f;
-  if (i < n) {
-    int b = b0 + bg;
-    for (; b + 56 < b1; b += 64) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)(b + 8 * u) * n + i];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v[u];
-    }
-    for (; b < b1; b += 8) acc += ws[(int64_t)b * n + i];
-  }
-  part[bg][il] = acc;
-  __syncthreads();
-  if (bg == 0 && i < n) {
-    float t = 0.0f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) t += part[u][il];
-    const int k = i / C, cc = i % C;
-    atomicAdd(dw + cc * taps + k, t);
+  // per-block partial -> dw [C][taps] by float atomics in dw's own order (a wave-instruction adds 256 contiguous bytes: the
+  // shape the memory-side atomic units take at full rate; <= 1024 blocks x 10 KB = 8 us of atomic bandwidth).  r02 wrote the
+  // partials to a workspace and folded them with a second launch (dwconv_reduce_kernel: 22-36 us a time, 48 launches per step).
+  for (int o = threadIdx.x; o < taps * g.C; o += blockDim.x) {
+    const int cc = o / taps, k = o - cc * taps;
+    atomicAdd(ws + o, red[k * g.C + cc]);
   }
 }
 
@@ -509,7 +479,7 @@ __global__ __launch_bounds__(256) void dwconv_reduce_kernel(const float* __restr
 //   * the data gradient of a stride-1 pool is the same stencil with mirrored taps; the data gradient of a
 //     strided pool enumerates exactly the taps that reach an input position (1-2 per axis instead of 3 tests);
 //   * the weight gradient keeps one temporal tap per thread (72 accumulators), folds the threads of a block
-//     through LDS without atomics and writes one partial per block for dwconv_reduce_kernel.
+//     through LDS without atomics and adds one partial per block into dw with contiguous float atomics.
 
 struct RunGeom {
   PoolGeom g;
@@ -1437,14 +1407,13 @@ __global__ __launch_bounds__(256) void dw3_wgrad_kernel(const TD* __restrict__ d
 #pragma unroll
     for (int e = 0; e < CV; ++e) mine[k * CV + e] = acc[k][e];
   __syncthreads();
-  float* part = ws + (int64_t)blockIdx.x * 27 * g.C;
-  for (int o = threadIdx.x; o < 27 * g.C; o += 256) {
-    const int tap = o / g.C, ch = o - tap * g.C;
+  for (int o = threadIdx.x; o < 27 * g.C; o += 256) {   // o walks dw [C][27]: contiguous float atomics (see dwconv_bwd_weight_kernel)
+    const int ch = o / 27, tap = o - ch * 27;
     const int okt = tap / 9, k9 = tap - okt * 9;
     const int oc = ch / CV, oe = ch - oc * CV;
     float sum = 0.0f;
     for (int s3 = 0; s3 < slots3; ++s3) sum += red3[((s3 * 3 + okt) * r.cpr + oc) * PITCH + k9 * CV + oe];
-    part[o] = sum;
+    atomicAdd(ws + o, sum);
   }
 }
 
@@ -1550,14 +1519,13 @@ __global__ __launch_bounds__(256) void dw3_wgrad_march_kernel(const TD* __restri
 #pragma unroll
     for (int e = 0; e < CV; ++e) mine[k * CV + e] = acc[k][e];
   __syncthreads();
-  float* part = ws + (int64_t)blockIdx.x * 27 * g.C;
-  for (int o = threadIdx.x; o < 27 * g.C; o += 256) {
-    const int tap = o / g.C, ch = o - tap * g.C;
+  for (int o = threadIdx.x; o < 27 * g.C; o += 256) {   // o walks dw [C][27]: contiguous float atomics (see dwconv_bwd_weight_kernel)
+    const int ch = o / 27, tap = o - ch * 27;
     const int okt = tap / 9, okh = (tap - okt * 9) / 3, okw = tap % 3;
     const int oc = ch / CV, oe = ch - oc * CV;
     float sum = 0.0f;
     for (int s3 = 0; s3 < slots3; ++s3) sum += red3[((s3 * 3 + okh) * r.cpr + oc) * PITCH + (okt * 3 + okw) * CV + oe];
-    part[o] = sum;
+    atomicAdd(ws + o, sum);
   }
 }
 
@@ -1921,10 +1889,11 @@ extern "C" int dcc_pool_bwd_data(const void* dy, void* dx, const float* w, const
   return dcc_check_launch();
 }
 
-// dw [C][taps] fp32 is ACCUMULATED into.  workspace: fp32 [DCC_DWCONV_WS_BLOCKS * taps * C] scratch (no init needed).
+// dw [C][taps] fp32 is ACCUMULATED into (float atomics, one 10-KB partial per block).  workspace: unused, may be null.
 extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, float* workspace, const int* dims,
                                      const int64_t* strides, int dtype, int grad_dtype, void* stream) {
-  if (!dy || !x || !dw || !workspace || !dims || !strides) return DCC_ERR_ARG;
+  if (!dy || !x || !dw || !dims || !strides) return DCC_ERR_ARG;
+  (void)workspace;   // r02's per-block partial slabs: unused since every block adds into dw itself (kept in the ABI)
   PoolGeom g = make_geom(dims, strides);
   int rc = geom_ok(g, dtype == DCC_BF16 ? 8 : 4);
   if (rc) return rc;
@@ -1961,10 +1930,10 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
   } while (0)
 #define DW3W(T_, TD_, S_)                                                                                           \
   do {                                                                                                              \
-    if (march && WM == 4) DW3K((dw3_wgrad_march_kernel<T_, TD_, S_, 4>), (const TD_*)dy, (const T_*)x, workspace, r, iters, nruns); \
-    else if (march) DW3K((dw3_wgrad_march_kernel<T_, TD_, S_, 2>), (const TD_*)dy, (const T_*)x, workspace, r, iters, nruns); \
-    else if (w7) DW3K((dw3_wgrad_kernel<T_, TD_, S_, 7>), (const TD_*)dy, (const T_*)x, workspace, r, iters);       \
-    else DW3K((dw3_wgrad_kernel<T_, TD_, S_, 4>), (const TD_*)dy, (const T_*)x, workspace, r, iters);               \
+    if (march && WM == 4) DW3K((dw3_wgrad_march_kernel<T_, TD_, S_, 4>), (const TD_*)dy, (const T_*)x, dw, r, iters, nruns); \
+    else if (march) DW3K((dw3_wgrad_march_kernel<T_, TD_, S_, 2>), (const TD_*)dy, (const T_*)x, dw, r, iters, nruns); \
+    else if (w7) DW3K((dw3_wgrad_kernel<T_, TD_, S_, 7>), (const TD_*)dy, (const T_*)x, dw, r, iters);       \
+    else DW3K((dw3_wgrad_kernel<T_, TD_, S_, 4>), (const TD_*)dy, (const T_*)x, dw, r, iters);               \
   } while (0)
 #define DW3W_ALL(T_, TD_) do { if (S == 1) DW3W(T_, TD_, 1); else if (S == 2) DW3W(T_, TD_, 2); else if (S == 4) DW3W(T_, TD_, 4); else DW3W(T_, TD_, 8); } while (0)
       bool done = true;
@@ -1976,12 +1945,7 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
 #undef DW3W_ALL
 #undef DW3W
 #undef DW3K
-      if (done) {
-        rc = dcc_check_launch();
-        if (rc) return rc;
-        hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((27 * g.C + 31) / 32, (nblocks + 63) / 64), dim3(256), 0, s, workspace, dw, nblocks, 27, g.C);
-        return dcc_check_launch();
-      }
+      if (done) return dcc_check_launch();   // every block added its partial into dw itself
     }
   }
   const int cv = dtype == DCC_BF16 ? 8 : 4;
@@ -1993,14 +1957,11 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
   dim3 grid(blocks_for(total, slots * 4, 1024));  // <= DCC_DWCONV_WS_BLOCKS
   const size_t lds = (size_t)taps * g.C * 4;
   if (dtype == DCC_BF16 && grad_dtype == DCC_BF16)
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, workspace, g);
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, dw, g);
   else if (dtype == DCC_BF16 && grad_dtype == DCC_F32)
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, float>), grid, dim3(256), lds, s, (const float*)dy, (const bf16_t*)x, workspace, g);
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, float>), grid, dim3(256), lds, s, (const float*)dy, (const bf16_t*)x, dw, g);
   else if (dtype == DCC_F32 && grad_dtype == DCC_F32)
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<float, float>), grid, dim3(256), lds, s, (const float*)dy, (const float*)x, workspace, g);
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<float, float>), grid, dim3(256), lds, s, (const float*)dy, (const float*)x, dw, g);
   else return DCC_ERR_UNSUPPORTED;
-  rc = dcc_check_launch();
-  if (rc) return rc;
-  hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((taps * g.C + 31) / 32, (grid.x + 63) / 64), dim3(256), 0, s, workspace, dw, (int)grid.x, taps, g.C);
   return dcc_check_launch();
 }

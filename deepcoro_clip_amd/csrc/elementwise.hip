@@ -459,9 +459,32 @@ __global__ __launch_bounds__(256) void fp8_quant_t_kernel(const T* __restrict__ 
   }
 }
 
+// dst[c][r] = (bf16) src[r][c]: the transposed bf16 shadow of an fp32 weight (the streaming GEMM takes W as [N][K] rows, a
+// data-gradient product g W needs W^T in that form); 32 x 32 tiles through LDS, weights only (<= a few MB per step)
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, int64_t lds_, bf16_t* __restrict__ dst,
+                                                             int64_t ldd, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int r = r0 + i / 32, c = c0 + i % 32;
+    tile[i / 32][i % 32] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] : 0.0f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int c = c0 + i / 32, r = r0 + i % 32;
+    if (c < cols && r < rows) dst[(int64_t)c * ldd + r] = (bf16_t)tile[i % 32][i / 32];
+  }
+}
+
 }  // namespace
 
 #define ST (hipStream_t) stream
+
+extern "C" int dcc_cast_transpose(const float* src, int64_t lds_, void* dst, int64_t ldd, int rows, int cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return DCC_ERR_ARG;
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, ST, src, lds_, (bf16_t*)dst, ldd, rows, cols);
+  return dcc_check_launch();
+}
 
 // gate == NULL: y = relu(x);  gate != NULL: y = x * [gate > 0]  (backward with gate = the forward output)
 extern "C" int dcc_relu(const void* x, const void* gate, void* y, int64_t n, int dtype, void* stream) {

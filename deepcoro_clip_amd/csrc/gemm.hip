@@ -609,6 +609,15 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
     const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, variant == 8 ? 256 : 128, variant == 11 ? 3 : 4, st);
     if (rc != DCC_ERR_UNSUPPORTED) return rc;
   }
+  // Early MViT blocks (C = 96 / 192 at 10^5 - 10^6 rows): HBM-bound products with a reduction of a few k-steps — the streaming
+  // panel kernel keeps the weight in LDS and every wave on its own rows (gemm_stream.hip).  Chosen when the whole reduction fits a
+  // wave's registers and either the reduction or the output row is short; DCC_STREAM_GEMM=0 restores the tiled kernels (A/B).
+  static const int stream_mode = getenv("DCC_STREAM_GEMM") ? atoi(getenv("DCC_STREAM_GEMM")) : 1;
+  if (stream_mode && in_dtype == DCC_BF16 && out_dtype == DCC_BF16 && aligned && variant == 0 && !a_km && !b_km && batch == 1 &&
+      splitk == 1 && !(flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && M >= 16384 && K <= 576 && (K <= 192 || N <= 192)) {
+    const int rc = dcc_gemm_stream_launch(p, st);
+    if (rc != DCC_ERR_UNSUPPORTED) return rc;
+  }
   // Measured on MI355X (tools/gemm_bench.py, profiles/r02_kernel_bench.txt): forward GEMMs with a short reduction and a
   // wide output (fc1: N = 4C, qkv: N = 3C; K = C <= 768) run 12-15 % faster on 256 x 256 tiles with 8 unspecialised
   // waves (half the L2 -> LDS operand traffic per FLOP) than on the ring kernel's 128 x 128 tiles; N = C outputs, k-major

@@ -39,3 +39,6 @@ int dcc_gemm_ring_launch(const GemmParams& p, int a_km, int b_km, int out_dtype,
 int dcc_gemm_ring_launch_fp8(const GemmParams& p, hipStream_t stream);
 // Wide-tile kernel (gemm_wide.hip): 256 x bn tiles (bn = 256 | 128), 8 waves.  DCC_ERR_UNSUPPORTED outside its domain.
 int dcc_gemm_wide_launch(const GemmParams& p, int a_km, int b_km, int out_dtype, int bn, int ns, hipStream_t stream);
+// Streaming panel kernel (gemm_stream.hip): row-major bf16 A [M,K] x W [N,K]^T -> bf16 with the weight resident in LDS, for the
+// early MViT blocks' short-reduction GEMMs (K in {96, 192, 288, 384, 576}, N % 32 == 0).  DCC_ERR_UNSUPPORTED outside its domain.
+int dcc_gemm_stream_launch(const GemmParams& p, hipStream_t stream);

@@ -48,6 +48,31 @@ def wcast(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return t
 
 
+def wcast_t(w: torch.Tensor) -> torch.Tensor:
+    """Transposed bf16 shadow [K, N] of an fp32 weight [N, K], cached on the parameter like `wcast`'s shadows; the optimizer's
+    `invalidate_weight_cache()` retires it once per step (one small transpose launch per weight and step)."""
+    owner = w._base if w._base is not None else w
+    cache = owner.__dict__.setdefault("_dcc_shadows_t", {})
+    key = (w.storage_offset(), tuple(w.shape), tuple(w.stride()))
+    stamp = (owner._version, _WEPOCH, owner.data_ptr())
+    hit = cache.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    t = K.cast_transpose(w.detach())
+    cache[key] = (stamp, t)
+    return t
+
+
+def _dx_gemm(g: torch.Tensor, weight: torch.Tensor, wc: torch.Tensor, **kw) -> torch.Tensor:
+    """g [rows, N] @ W [N, Kd] (the data gradient of a Linear layer, W k-major for the GEMM).  Where the product is in the
+    streaming panel kernel's domain (early MViT blocks) it runs there on a transposed weight shadow; else on the tiled kernels'
+    k-major operand path."""
+    if weight is not None and weight.dtype == torch.float32 and weight.dim() == 2 and weight.stride(1) == 1 and \
+            K.stream_gemm_shape(g.shape[0], wc.shape[1], wc.shape[0], g.dtype):
+        return K.gemm(g, wcast_t(weight), **kw)
+    return K.gemm(g, wc, b_km=True, **kw)
+
+
 # ------------------------------------------------------------------------------ fp8 GEMM mode
 # BASELINE configs[4]: the towers' forward and data-gradient GEMMs in fp8 (block-scaled MFMA, per-tensor scales: e4m3 for
 # activations and weights, e5m2 for gradients), weight gradients stay bf16.  Switched on around the video trunk by
@@ -297,7 +322,7 @@ class LinearFn(torch.autograd.Function):
                 wt8, swt = wquant(ctx.params[0], True)
                 dx = K.gemm_fp8(g8, wt8, sg, swt, fmt_a=1).reshape(ctx.xshape)
             else:
-                dx = K.gemm(g, wc, b_km=True).reshape(ctx.xshape)
+                dx = _dx_gemm(g, ctx.params[0], wc).reshape(ctx.xshape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_db:  # bias gradient rides in the weight-gradient GEMM (column sums of its k-major A operand)
@@ -342,8 +367,8 @@ class Linear2Fn(torch.autograd.Function):
         g2 = _c(dy2).reshape(-1, wc2.shape[0])
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = K.gemm(g1, wc1, b_km=True)
-            dx = K.gemm(g2, wc2, b_km=True, resid=dx).reshape(ctx.xshape)
+            dx = _dx_gemm(g1, w1, wc1)
+            dx = _dx_gemm(g2, w2, wc2, resid=dx).reshape(ctx.xshape)
         grads = []
         for g, w, b, iw, ib in ((g1, w1, b1, 1, 2), (g2, w2, b2, 3, 4)):
             dw = db = None
@@ -417,7 +442,7 @@ class MlpFn(torch.autograd.Function):
             w2t8, s2t = wquant(ctx.params[2], True)
             dpre = K.gemm_fp8(g8, w2t8, sg, s2t, fmt_a=1, dgelu=True, aux=pre)
         else:
-            dpre = K.gemm(dy2, w2c, b_km=True, dgelu=True, aux=pre)
+            dpre = _dx_gemm(dy2, ctx.params[2], w2c, dgelu=True, aux=pre)
         if ctx.needs_input_grad[1]:
             db1 = (_grad_slots.take(ctx.params[1]) if ctx.needs_input_grad[2] else None)
             if db1 is None and ctx.needs_input_grad[2]:
@@ -431,7 +456,7 @@ class MlpFn(torch.autograd.Function):
                 w1t8, s1t = wquant(ctx.params[0], True)
                 dx = K.gemm_fp8(p8, w1t8, sp, s1t, fmt_a=1).reshape(ctx.xshape)
             else:
-                dx = K.gemm(dpre, w1c, b_km=True).reshape(ctx.xshape)
+                dx = _dx_gemm(dpre, ctx.params[0], w1c).reshape(ctx.xshape)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
 
 

@@ -153,6 +153,31 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
     return out
 
 
+STREAM_GEMM = _os.environ.get("DCC_STREAM_GEMM", "1") != "0"
+
+
+def stream_gemm_shape(M: int, N: int, K: int, dtype: torch.dtype) -> bool:
+    """Domain of the streaming panel GEMM (csrc/gemm_stream.hip, chosen inside dcc_gemm): bf16 row-major x row-major with the
+    weight resident in LDS — the early MViT blocks' products.  Mirrors the C-side test so that a data-gradient product
+    g W (k-major weight) can be handed over with a transposed weight shadow instead (functional._dx_gemm)."""
+    if not STREAM_GEMM or dtype != torch.bfloat16 or M < 16384 or K not in (96, 192, 288, 384, 576) or N % 32:
+        return False
+    if not (K <= 192 or N <= 192):
+        return False
+    nc = ((150 * 1024) // (2 * K + 16 + 4)) & ~31
+    return nc >= 32 and -(-N // nc) <= 4
+
+
+def cast_transpose(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [R, C] (row stride free) -> contiguous bf16 [C, R]."""
+    L.require_cuda(w)
+    assert w.dim() == 2 and w.dtype == torch.float32 and w.stride(1) == 1
+    R, C = w.shape
+    out = torch.empty((C, R), device=w.device, dtype=torch.bfloat16)
+    L.call("dcc_cast_transpose", L.ptr(w), w.stride(0), L.ptr(out), R, R, C, L.stream())
+    return out
+
+
 def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias=None, a_km=False, b_km=False,
                  alpha: float = 1.0, accumulate: bool = False, splitk: int = 1):
     """Raw batched form (base tensors + explicit strides); `a`/`b`/`out` only provide base pointers and dtypes."""
@@ -389,19 +414,14 @@ def pool_bwd_data(dy: torch.Tensor, dx: torch.Tensor, g: PoolGeom, weight: torch
     return dx
 
 
-_DWCONV_WS: dict = {}
 
 
 def dwconv_bwd_weight(dy: torch.Tensor, x: torch.Tensor, g: PoolGeom, dw: torch.Tensor):
-    """dw fp32 [C, taps] accumulated into (per-block partials go through a cached scratch buffer, no atomics)."""
+    """dw fp32 [C, taps] accumulated into: every block folds its threads in LDS and adds its partial with contiguous float
+    atomics (one launch; r02 wrote per-block slabs to a scratch buffer and folded them with a second kernel)."""
     L.require_cuda(dy, x, dw)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
-    n = 1024 * g.C * g.kernel[0] * g.kernel[1] * g.kernel[2]  # DCC_DWCONV_WS_BLOCKS x taps x C
-    key = (dy.device.index, n, L.stream())  # one scratch buffer per stream: the
-    ws = _DWCONV_WS.get(key)                                                      # q/k/v branches run concurrently
-    if ws is None:
-        ws = _DWCONV_WS[key] = torch.empty(n, device=dy.device, dtype=torch.float32)
-    L.call("dcc_dwconv_bwd_weight", L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(ws), g.dims(), _pool_strides(x, dy), L.dt(x),
+    L.call("dcc_dwconv_bwd_weight", L.ptr(dy), L.ptr(x), L.ptr(dw), None, g.dims(), _pool_strides(x, dy), L.dt(x),
            L.dt(dy), L.stream())
     return dw
 

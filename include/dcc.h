@@ -40,7 +40,7 @@ extern "C" {
 #define DCC_GEMM_ACCUM 32
 #define DCC_GEMM_COLSUM_A 64 /* colsum[m] += sum_k A(m,k): bias gradient fused into the k-major weight-gradient GEMM */
 #define DCC_OPT_CHUNK 4096
-#define DCC_DWCONV_WS_BLOCKS 1024 /* dcc_dwconv_bwd_weight workspace = this x taps x C floats */
+#define DCC_DWCONV_WS_BLOCKS 1024 /* upper bound of dcc_dwconv_bwd_weight's grid (its `workspace` argument is unused since r03) */
 
 int dcc_version(void);
 
@@ -170,6 +170,9 @@ int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, float* works
 int dcc_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 int dcc_cast2d(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int cols, int src_dtype,
                int dst_dtype, void* stream);
+/* dst[c][r] = bf16(src[r][c]): transposed bf16 shadow of an fp32 weight [rows, cols] (lds_ / ldd: row pitches in elements).  The
+ * data-gradient product dX = dY W of the early MViT blocks runs on the streaming GEMM, which takes its weight as [N][K] rows. */
+int dcc_cast_transpose(const float* src, int64_t lds_, void* dst, int64_t ldd, int rows, int cols, void* stream);
 int dcc_axpby(void* out, float a, const void* x, float b, const void* y, int64_t n, int dtype, void* stream);
 int dcc_dgelu_mul(const void* dy, const void* pre, void* out, int64_t n, int dtype, void* stream);
 /* uint8 frames -> (x - mean[c]) / std[c] fp32, channel innermost (v2.Normalize of utils/video.py:278-288 moved to the GPU:
