@@ -609,12 +609,20 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
     const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, variant == 8 ? 256 : 128, variant == 11 ? 3 : 4, st);
     if (rc != DCC_ERR_UNSUPPORTED) return rc;
   }
-  // Early MViT blocks (C = 96 / 192 at 10^5 - 10^6 rows): HBM-bound products with a reduction of a few k-steps — the streaming
-  // panel kernel keeps the weight in LDS and every wave on its own rows (gemm_stream.hip).  Chosen when the whole reduction fits a
-  // wave's registers and either the reduction or the output row is short; DCC_STREAM_GEMM=0 restores the tiled kernels (A/B).
+  // Early MViT blocks (C = 96 / 192 at 10^5 - 10^6 rows): HBM-bound products with a reduction of a few k-steps.  The streaming
+  // panel kernel (gemm_stream.hip: weight resident in LDS, every wave on its own rows, no barriers) was built for all of them and
+  // MEASURED against the tiled kernels (tools/stream_bench.py, profiles/r03_stream_bench.txt): it wins only where the output is wide
+  // and the epilogue is a plain bias — qkv of blocks 0-3: 1.06-1.22x — and loses everywhere else (N = C outputs 0.63-0.98x: the
+  // tiled kernels already stream those at 4.5-5.3 TB/s; two-tensor / gelu' epilogues 0.34-0.62x: a lane's 16-byte pieces cover
+  // only 32 bytes of a row per store instruction, which the non-temporal pre-activation path turns into partial-line HBM writes).
+  // So it takes exactly the shapes it wins; DCC_STREAM_GEMM=0 disables it, =2 (or variant 12: tests, tools/stream_bench.py) widens
+  // it to its whole domain.
   static const int stream_mode = getenv("DCC_STREAM_GEMM") ? atoi(getenv("DCC_STREAM_GEMM")) : 1;
-  if (stream_mode && in_dtype == DCC_BF16 && out_dtype == DCC_BF16 && aligned && variant == 0 && !a_km && !b_km && batch == 1 &&
-      splitk == 1 && !(flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && M >= 16384 && K <= 576 && (K <= 192 || N <= 192)) {
+  const bool stream_all = stream_mode == 2 || variant == 12;
+  if ((stream_mode || variant == 12) && in_dtype == DCC_BF16 && out_dtype == DCC_BF16 && aligned && (variant == 0 || variant == 12) &&
+      !a_km && !b_km && batch == 1 && splitk == 1 && !(flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && M >= 16384 && K <= 576 &&
+      (K <= 192 || N <= 192) &&
+      (stream_all || (K <= 192 && N >= 288 && !(flags & (GEMM_GELU | GEMM_DGELU | GEMM_SAVE_PRE | GEMM_RESID))))) {
     const int rc = dcc_gemm_stream_launch(p, st);
     if (rc != DCC_ERR_UNSUPPORTED) return rc;
   }

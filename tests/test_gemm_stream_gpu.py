@@ -8,6 +8,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def whole_domain():
+    """Variant 12 sends every shape of the streaming kernel's domain to it (the default dispatch keeps only the shapes it wins:
+    plain wide outputs, csrc/gemm.hip), for the forward products and — through functional._dx_gemm — the data gradients."""
+    from deepcoro_clip_amd import kernels as K
+
+    old = K.GEMM_VARIANT
+    K.GEMM_VARIANT = 12 << 8
+    yield
+    K.GEMM_VARIANT = old
+
+
 def _tiled(K):
     """Context: the same call on the tiled ring kernel (variant 10: neither the wide nor the streaming kernel is chosen)."""
     class _Ctx:

@@ -60,7 +60,7 @@ tot = [0.0, 0.0]
 for tag, M, N, Kd, kw in SHAPES:
     nbytes = 2 * (M * Kd + N * Kd + M * N * (1 + int(bool(kw.get("resid"))) + int(bool(kw.get("save_pre"))) + int(bool(kw.get("dgelu")))))
     t_ring = run(M, N, Kd, kw, 10)
-    t_stream = run(M, N, Kd, kw, 0)
+    t_stream = run(M, N, Kd, kw, 12)
     tot[0] += t_ring; tot[1] += t_stream
     print(f"{tag:20s} M{M} N{N} K{Kd}: tiled {t_ring:7.1f} us ({nbytes / t_ring / 1e6:5.2f} TB/s)   streaming {t_stream:7.1f} us "
           f"({nbytes / t_stream / 1e6:5.2f} TB/s, {2.0 * M * N * Kd / t_stream / 1e6:6.1f} TFLOP/s)   x{t_ring / t_stream:4.2f}", flush=True)
