@@ -55,6 +55,52 @@ def block_plan(temporal_size: int, spatial_size: Sequence[int]):
     return plan
 
 
+class _DepthwiseConv3dTaps(torch.autograd.Function):
+    """Depthwise 3 x 3 x 3 convolution (padding 1, stride (st, sh, sw), no bias) on channels-LAST grids [..., T, H, W, C]:
+    out[..., t, h, w, c] = sum over the 27 taps of weight[c, 0, dt, dh, dw] * x_padded[..., t*st + dt, h*sh + dh, w*sw + dw, c]
+    — the arithmetic of nn.Conv3d(C, C, 3, stride, padding=1, groups=C, bias=False) (torchvision mvit.Pool's `pool`), written as
+    27 strided-slice multiply-adds with a hand-written backward of the same form.  ATen's CPU paths for depthwise 3-D
+    convolutions (slow_conv3d_forward in fp64, convolution_backward in both precisions) took 40 % of the oracle's time and need
+    a channels-first copy of every q / k / v tensor; equality with F.conv3d is checked in tests/test_oracle_golden.py."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride):
+        st, sh, sw = stride
+        T, H, W, C = x.shape[-4:]
+        To, Ho, Wo = (T - 1) // st + 1, (H - 1) // sh + 1, (W - 1) // sw + 1
+        xp = F.pad(x, (0, 0, 1, 1, 1, 1, 1, 1))
+        out = torch.zeros(*x.shape[:-4], To, Ho, Wo, C, dtype=x.dtype)
+        for dt in range(3):
+            for dh in range(3):
+                for dw in range(3):
+                    sl = xp[..., dt:dt + st * (To - 1) + 1:st, dh:dh + sh * (Ho - 1) + 1:sh, dw:dw + sw * (Wo - 1) + 1:sw, :]
+                    out.addcmul_(sl, weight[:, 0, dt, dh, dw])
+        ctx.save_for_backward(xp, weight)
+        ctx.stride, ctx.out_thw = stride, (To, Ho, Wo)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight = ctx.saved_tensors
+        st, sh, sw = ctx.stride
+        To, Ho, Wo = ctx.out_thw
+        dxp = torch.zeros_like(xp)
+        dw = torch.zeros_like(weight)
+        red = tuple(range(dy.dim() - 1))
+        for dt in range(3):
+            for dh in range(3):
+                for dw_ in range(3):
+                    idx = (Ellipsis, slice(dt, dt + st * (To - 1) + 1, st), slice(dh, dh + sh * (Ho - 1) + 1, sh),
+                           slice(dw_, dw_ + sw * (Wo - 1) + 1, sw), slice(None))
+                    dxp[idx].addcmul_(dy, weight[:, 0, dt, dh, dw_])
+                    dw[:, 0, dt, dh, dw_] = (xp[idx] * dy).sum(dim=red)
+        return dxp[..., 1:-1, 1:-1, 1:-1, :], dw, None
+
+
+def depthwise_conv3d_taps(x, weight, stride):
+    return _DepthwiseConv3dTaps.apply(x, weight, tuple(stride))
+
+
 class Pool(nn.Module):
     """torchvision mvit.Pool: split class token, pool the (T,H,W) grid, re-attach, then norm (norm covers the class token)."""
 
@@ -67,6 +113,15 @@ class Pool(nn.Module):
         # x: [B, heads, N, C]
         cls, x = x[:, :, :1], x[:, :, 1:]
         B, Hh, N, C = x.shape
+        p = self.pool
+        if isinstance(p, nn.Conv3d) and p.groups == C and p.kernel_size == (3, 3, 3) and p.padding == (1, 1, 1) and p.bias is None:
+            # the q / k / v pools: same arithmetic as `self.pool(x)` on the channels-first grid, without ATen's slow depthwise path
+            y = depthwise_conv3d_taps(x.reshape(B, Hh, *thw, C), p.weight, p.stride)
+            T, H, W = y.shape[2:5]
+            x = torch.cat((cls, y.reshape(B, Hh, T * H * W, C)), dim=2)
+            if self.norm_act is not None:
+                x = self.norm_act(x)
+            return x, (T, H, W)
         x = x.transpose(2, 3).reshape(B * Hh, C, *thw)
         x = self.pool(x)
         T, H, W = x.shape[2:]

@@ -308,3 +308,35 @@ def test_masked_pools_oracle_matches_reference():
         for n in (4, 8):
             y = ag(_t(g[f"ag_x{n}"]), torch.from_numpy(g[f"ag_m{n}"]))
             assert np.allclose(y.numpy(), g[f"ag_y{n}"], atol=2e-5), n
+
+
+@pytest.mark.parametrize("stride", [(1, 1, 1), (1, 2, 2), (1, 4, 4), (1, 8, 8), (2, 2, 2)])
+def test_oracle_depthwise_pool_equals_aten_conv3d(stride):
+    """oracle/mvit.py restates the q / k / v pools' nn.Conv3d(groups=C, k=3, p=1, bias=False) as 27 strided-slice multiply-adds
+    with a hand-written backward (ATen's CPU depthwise paths took 40 % of the oracle's time): forward, input gradient and weight
+    gradient against F.conv3d in fp64, and the Pool module's two code paths against each other."""
+    import torch.nn.functional as F
+
+    from oracle.mvit import Pool, depthwise_conv3d_taps
+
+    g = torch.Generator().manual_seed(sum(stride))
+    B, Hh, C, thw = 2, 3, 8, (4, 16, 12)
+    x = torch.randn(B, Hh, *thw, C, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(C, 1, 3, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    y = depthwise_conv3d_taps(x, w, stride)
+    xr, wr = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    yr = F.conv3d(xr.permute(0, 1, 5, 2, 3, 4).reshape(B * Hh, C, *thw), wr, None, stride, (1, 1, 1), groups=C)
+    yr = yr.reshape(B, Hh, C, *yr.shape[2:]).permute(0, 1, 3, 4, 5, 2)
+    assert y.shape == yr.shape and (y - yr).abs().max() < 1e-12
+    up = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(up)
+    yr.backward(up)
+    assert (x.grad - xr.grad).abs().max() < 1e-12 and (w.grad - wr.grad).abs().max() < 1e-11
+    # the module: depthwise conv -> tap path; anything else (the skip path's MaxPool3d) -> the module's own forward
+    conv = torch.nn.Conv3d(C, C, (3, 3, 3), stride=stride, padding=(1, 1, 1), groups=C, bias=False).double()
+    tok = torch.randn(B, Hh, 1 + thw[0] * thw[1] * thw[2], C, generator=g, dtype=torch.float64)
+    out, out_thw = Pool(conv, torch.nn.LayerNorm(C).double())(tok, thw)
+    ref = conv(tok[:, :, 1:].transpose(2, 3).reshape(B * Hh, C, *thw))
+    assert tuple(ref.shape[2:]) == out_thw
+    ref = torch.cat((tok[:, :, :1], ref.reshape(B, Hh, C, -1).transpose(2, 3)), dim=2)
+    assert (out - torch.nn.functional.layer_norm(ref, (C,))).abs().max() < 1e-10
