@@ -365,6 +365,19 @@ __global__ void relu_kernel(const T* __restrict__ x, const T* __restrict__ gate,
 }
 
 // ---- fp8 quantisation (per-tensor scale) for the fp8 GEMMs of BASELINE configs[4] ------------------------------------
+// One atomicMax per BLOCK on the tensor's amax word (waves fold through LDS first), from a grid of at most 1024 blocks: atomics
+// on one address retire serially at ~12 ns each, and the first versions' one atomic per WAVE (19-33 k of them) was the whole
+// cost of quantising an activation — 230 of 260 us for a [50 208, 384] tensor (tools/gemm_bench.py, r03).
+__device__ __forceinline__ void block_amax(float m, float* __restrict__ amax) {
+  __shared__ float part[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    if (m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));
+  }
+}
 // amax[0] = max(amax[0], max |x|): float bit patterns of non-negative values order like unsigned integers
 template <typename T>
 __global__ void absmax_kernel(const T* __restrict__ x, int64_t rows, int64_t cols, int64_t ldx, float* __restrict__ amax) {
@@ -372,8 +385,7 @@ __global__ void absmax_kernel(const T* __restrict__ x, int64_t rows, int64_t col
   const int64_t n = rows * cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     m = fmaxf(m, fabsf(to_f32(x[(i / cols) * ldx + (i % cols)])));
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));
+  block_amax(m, amax);
 }
 __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d, float lim, int bf8) {
   a = fminf(fmaxf(a, -lim), lim); b = fminf(fmaxf(b, -lim), lim); c = fminf(fmaxf(c, -lim), lim); d = fminf(fmaxf(d, -lim), lim);
@@ -411,8 +423,7 @@ __global__ __launch_bounds__(256) void absmax_bf16_flat_kernel(const uint4* __re
       m = max(m, hi > 0x7f80u ? 0u : hi);
     }
   }
-  float f = wave_max(__uint_as_float(m << 16));
-  if ((threadIdx.x & 63) == 0 && f > 0.0f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(f));
+  block_amax(__uint_as_float(m << 16), amax);
 }
 __global__ __launch_bounds__(256) void fp8_quant_bf16_flat_kernel(const uint4* __restrict__ x, int64_t n8, const float* __restrict__ amax,
                                                                   uint2* __restrict__ out, float fmax_, int bf8,
@@ -499,10 +510,13 @@ extern "C" int dcc_absmax(const void* x, int64_t rows, int64_t cols, int64_t ldx
   if (!x || !amax || rows <= 0 || cols <= 0) return DCC_ERR_ARG;
   if (dtype == DCC_BF16 && ldx == cols && ((rows * cols) % 8) == 0 && !((uintptr_t)x & 15)) {
     const int64_t n8 = rows * cols / 8;
-    hipLaunchKernelGGL(absmax_bf16_flat_kernel, dim3(gs_blocks(n8, 2)), dim3(256), 0, ST, (const uint4*)x, n8, amax);
+    unsigned gb = gs_blocks(n8, 2);
+    if (gb > 1024) gb = 1024;
+    hipLaunchKernelGGL(absmax_bf16_flat_kernel, dim3(gb), dim3(256), 0, ST, (const uint4*)x, n8, amax);
     return dcc_check_launch();
   }
   dim3 g(gs_blocks(rows * cols, 8));
+  if (g.x > 1024) g.x = 1024;
   if (dtype == DCC_BF16) hipLaunchKernelGGL((absmax_kernel<bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)x, rows, cols, ldx, amax);
   else if (dtype == DCC_F32) hipLaunchKernelGGL((absmax_kernel<float>), g, dim3(256), 0, ST, (const float*)x, rows, cols, ldx, amax);
   else return DCC_ERR_UNSUPPORTED;

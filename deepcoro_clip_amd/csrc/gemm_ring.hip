@@ -401,7 +401,11 @@ constexpr int NT2 = 64 * 12;
 // rows, pieces and swizzle — and the consumers run 8 block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales, the
 // per-tensor scales ride in alpha) instead of 16 bf16 MFMAs per K-step: half the K-steps per tile at the same step cost.
 typedef int v8i32 __attribute__((ext_vector_type(8)));
-template <bool A_KM, bool B_KM, bool F8>
+// FMT (F8 only): element formats as compile-time constants, bit 0 = A (0 e4m3, 1 e5m2), bit 1 = B.  r02 branched on p.fmt_a /
+// p.fmt_b around every MFMA: hipcc then kept the accumulators in scratch (a 16-register spill + 19 wait states behind each
+// v_mfma_scale) and selected the zero C-input with 16 v_cndmask per MFMA — the fp8 GEMM ran at HALF the bf16 rate
+// (profiles/r03_a_kernel_bench_fp8_before_quantiser_fix.txt: 8192^3 458 vs 846 TFLOP/s).
+template <bool A_KM, bool B_KM, bool F8, int FMT = 0>
 __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo geo) {
   constexpr int NS = NS2, D = NS - 1, PPL = 4;
   constexpr int ES = F8 ? 1 : 2;          // operand element size
@@ -580,20 +584,24 @@ __global__ __launch_bounds__(NT2, 1) void gemm_ring2_kernel(GemmParams p, Geo ge
           const int cur = s & 1;
           if (s + 1 < 2) fetch8(cur ^ 1, s + 1);
           __builtin_amdgcn_sched_barrier(0);
-          const bool first = (s == 0 && kt == 0);
-          const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
           constexpr int ONE = 0x7f7f7f7f;  // E8M0 block scale 2^0 in every byte
-          // swapped operands (C^T), formats from the launch: 0 = e4m3, 1 = e5m2 (uniform branch)
+          // swapped operands (C^T): source A of the instruction is this kernel's B fragment (cbsz = its format), source B the A
+          // fragment (blgp); the first MFMA of a tile starts from C = 0 (inline constant), like the bf16 path
+          constexpr int FA = FMT & 1, FB = (FMT >> 1) & 1;
+          if (s == 0 && kt == 0) {
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const f32x16 cin = first ? zero : acc[i][j];
-              if (p.fmt_a == 0 && p.fmt_b == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(gb[cur][j], ga[cur][i], cin, 0, 0, 0, ONE, 0, ONE);
-              else if (p.fmt_a == 1 && p.fmt_b == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(gb[cur][j], ga[cur][i], cin, 0, 1, 0, ONE, 0, ONE);
-              else if (p.fmt_a == 0 && p.fmt_b == 1) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(gb[cur][j], ga[cur][i], cin, 1, 0, 0, ONE, 0, ONE);
-              else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(gb[cur][j], ga[cur][i], cin, 1, 1, 0, ONE, 0, ONE);
-            }
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(gb[cur][j], ga[cur][i], zero, FB, FA, 0, ONE, 0, ONE);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(gb[cur][j], ga[cur][i], acc[i][j], FB, FA, 0, ONE, 0, ONE);
+          }
         }
       } else {
         bf16x8 fa[2][2], fb[2][2];
@@ -837,16 +845,27 @@ int dcc_gemm_ring_launch_fp8(const GemmParams& p, hipStream_t st) {
   geo.per = geo.ksteps;
   if (geo.ksteps < 2) return DCC_ERR_UNSUPPORTED;
   constexpr int LDS2 = NS2 * STAGE_B + MB_B;
-  auto kern = gemm_ring2_kernel<false, false, true>;
-  static bool cfg = false;
-  if (!cfg) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return DCC_ERR_LAUNCH;
-    cfg = true;
-  }
+  if ((p.fmt_a != 0 && p.fmt_a != 1) || (p.fmt_b != 0 && p.fmt_b != 1)) return DCC_ERR_ARG;
   int G = num_cus() & ~7;
   if (G < 8) G = 8;
   const int need = (geo.items + 7) & ~7;
   if (G > need) G = need;
-  hipLaunchKernelGGL(kern, dim3(G), dim3(NT2), LDS2, st, p, geo);
+#define F8_LAUNCH(FMT_)                                                                                                          \
+  do {                                                                                                                           \
+    auto kern = gemm_ring2_kernel<false, false, true, FMT_>;                                                                     \
+    static bool cfg = false;                                                                                                     \
+    if (!cfg) {                                                                                                                  \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return DCC_ERR_LAUNCH; \
+      cfg = true;                                                                                                                \
+    }                                                                                                                            \
+    hipLaunchKernelGGL(kern, dim3(G), dim3(NT2), LDS2, st, p, geo);                                                              \
+  } while (0)
+  switch (p.fmt_a | (p.fmt_b << 1)) {
+    case 0: F8_LAUNCH(0); break;
+    case 1: F8_LAUNCH(1); break;
+    case 2: F8_LAUNCH(2); break;
+    default: F8_LAUNCH(3); break;
+  }
+#undef F8_LAUNCH
   return dcc_check_launch();
 }

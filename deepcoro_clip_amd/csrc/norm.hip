@@ -354,6 +354,10 @@ int ln_bwd_t(const void* dy, int64_t lddy, const void* x, int64_t ldx, const flo
   // few rows (the text tower's 768-token norms, the aggregator): a grid of <= 128 blocks pays ~2 us for the atomic tail,
   // less than the fold kernel's launch
   if (ws && rows <= 128 * 8) ws = nullptr;
+  // DCC_LN_ATOMIC=1 (A/B): always the one-launch form — every block adds its dgamma / dbeta partial with contiguous float
+  // atomics (256 bytes per wave-instruction) instead of storing it for ln_reduce_kernel
+  static const bool ln_atomic = getenv("DCC_LN_ATOMIC") && atoi(getenv("DCC_LN_ATOMIC")) != 0;
+  if (ln_atomic) ws = nullptr;
   static const int lnb_u = getenv("DCC_LNB_U") ? atoi(getenv("DCC_LNB_U")) : 2;
 #define LN_BU(LP, IT, UU) hipLaunchKernelGGL((ln_bwd_kernel<T, TD, LP, IT, UU>), dim3(nb = lnb_grid(rows, 64 / LP * UU, ws ? ws_cap : lnb_cap)), dim3(256), 2 * C * sizeof(float), st, dyp, lddy, xp, ldx, mean, rstd, g, dxp, lddx, dgamma, dbeta, rows, C, drp, ws)
 #define LN_B(LP, IT) do { if (lnb_u == 4 && IT == 1) LN_BU(LP, IT, 4); else if (lnb_u >= 2 && IT <= 2) LN_BU(LP, IT, 2); else LN_BU(LP, IT, 1); } while (0)
