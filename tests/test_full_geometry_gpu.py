@@ -299,3 +299,41 @@ def test_loss_at_global_batch_4096_vs_fp64(kind):
     if kind == "bce":
         assert abs(crit.bias.grad.item() - bias_r.grad.item()) < 5e-4 * max(1e-3, abs(bias_r.grad.item()))
     assert math.isfinite(loss.item())
+
+
+@pytest.mark.parametrize("dtype,steps,tol", [(torch.float32, 3, 1e-4), (torch.bfloat16, 6, 1e-2)])
+def test_headline_config_loss_curve_vs_oracle(dtype, steps, tol):
+    """north_star: "loss curve matching CPU reference within 1e-2" on the 16-frame 224^2 multi-video config — the benchmark's own
+    workload (BASELINE configs[2] shard: N = 4 videos per study, AttentionPool + aggregator, 12-layer BERT-base, InfoNCE, clip,
+    AdamW), 2 studies, fresh random batches every step, the CPU oracle trained beside it with torch.optim.AdamW on the same
+    name-seeded weights.  fp32: 1e-4 per step; bf16: 1e-2 per step (the tiny-geometry curves are in tests/test_step_gpu.py)."""
+    from __graft_entry__ import make_tiny_setup
+    from oracle.losses import contrastive_loss
+
+    B, N = 2, 4
+    runner, (vo, to), _ = make_tiny_setup(dtype, B=B, T=16, S=224, seq=32, full_bert=True, pooling="attention", videos_per_study=N)
+    lt = torch.nn.Parameter(torch.log(torch.tensor([0.07])))
+    groups = [{"params": list(vo.model.parameters()), "lr": 1e-4, "weight_decay": 0.01},
+              {"params": list(vo.attention_pool.parameters()), "lr": 2e-4, "weight_decay": 0.01},
+              {"params": list(vo.aggregator.parameters()), "lr": 2e-4, "weight_decay": 0.01},
+              {"params": list(to.parameters()), "lr": 2e-5, "weight_decay": 0.01}, {"params": [lt], "lr": 1e-4}]
+    opt = torch.optim.AdamW(groups, lr=1e-4)
+    allp = list(vo.parameters()) + list(to.parameters())
+    g = torch.Generator().manual_seed(2024)
+    worst, curve = 0.0, []
+    for step in range(steps):
+        videos = torch.randn(B, N, 16, 224, 224, 3, generator=g)
+        ids = torch.randint(0, 30522, (B, 32), generator=g)
+        mask = torch.ones(B, 32, dtype=torch.int64)
+        mask[1, 24:] = 0
+        opt.zero_grad(set_to_none=True)
+        ref = contrastive_loss(vo(videos), to(ids, mask), lt)
+        ref.backward()
+        torch.nn.utils.clip_grad_norm_(allp, 5.0)
+        opt.step()
+        m, _ = runner._train_step(videos=videos.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda())
+        err = abs(m["loss"] - ref.item()) / max(1.0, abs(ref.item()))
+        curve.append((round(m["loss"], 5), round(ref.item(), 5)))
+        worst = max(worst, err)
+        assert err < tol, (step, curve)
+    print(f"[headline loss curve] {dtype}: (HIP, oracle) per step {curve}; worst relative deviation {worst:.2e}")
