@@ -143,3 +143,33 @@ def test_video_input_errors():
     with pytest.raises(ValueError):
         V.preprocess_frames(np.zeros((4, 8, 8, 2), np.uint8))
     assert V.frame_indices(3, 5) == [0, 1, 2, 2, 2] and V.frame_indices(10, 4) == [0, 3, 6, 9] and V.frame_indices(4, 4) == [0, 1, 2, 3]
+
+
+def test_run_epoch_prefetches_the_next_batch_on_a_side_stream():
+    """`_run_epoch` issues batch i+1's host -> device copies on a side stream before step i is enqueued (pinned batches: they run
+    under the step).  Same numbers as the in-line path (DCC_PREFETCH=0 / config.prefetch_batches=False), skipped batches are
+    tolerated, and the side stream is actually used."""
+    from __graft_entry__ import make_tiny_setup
+
+    def loader():
+        g = torch.Generator().manual_seed(77)
+        out = []
+        for i in range(4):
+            if i == 2:
+                out.append(None)   # a batch the collate function dropped
+            out.append({"videos": torch.randn(2, 4, 64, 64, 3, generator=g).pin_memory(),
+                        "encoded_texts": {"input_ids": torch.randint(0, 512, (2, 16), generator=g).pin_memory(),
+                                          "attention_mask": torch.ones(2, 16, dtype=torch.int64).pin_memory()}})
+        return out
+
+    results = []
+    for prefetch in (True, False):
+        runner, _, _ = make_tiny_setup(torch.float32)
+        runner._prefetch = prefetch
+        runner.train_loader = loader()
+        results.append((runner._run_epoch("train", 0), runner._h2d_stream is not None, runner.step))
+    (m1, used1, s1), (m0, used0, s0) = results
+    assert used1 and not used0 and s1 == s0 == 4
+    assert m1.keys() == m0.keys()
+    for k in m1:
+        assert abs(m1[k] - m0[k]) <= 1e-6 * max(1.0, abs(m0[k])), (k, m1[k], m0[k])
