@@ -244,8 +244,20 @@ def main():
     t_host = time.perf_counter() - t0  # launches enqueued; the metrics are not read, so nothing drained the queue yet
     barrier()
     dt = time.perf_counter() - t0
+    # host cost of a step WITHOUT queue back-pressure: in the free-running timed region a GPU-bound step makes the HIP queue fill
+    # up and the enqueue calls block, so `t_host` approaches the wall time whatever the host needs; one step launched into an
+    # EMPTY queue returns after the host's own work (Python + ctypes + hipLaunchKernel); median of three, outside the timed region
+    host_free = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        runner._train_step(**batch)
+        host_free.append(time.perf_counter() - th)
+    barrier()
+    host_free_ms = 1e3 * sorted(host_free)[1]
     if rank == 0:
-        print(f"[bench] host enqueue {1e3 * t_host / args.steps:.2f} ms/step, wall {1e3 * dt / args.steps:.2f} ms/step", file=sys.stderr, flush=True)
+        print(f"[bench] host enqueue {1e3 * t_host / args.steps:.2f} ms/step in the timed region (queue back-pressure included), "
+              f"{host_free_ms:.2f} ms/step into an empty queue; wall {1e3 * dt / args.steps:.2f} ms/step", file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -359,7 +371,7 @@ def main():
                        "study_pairs_per_s": round(pairs_per_step * args.steps / dt, 3),
                        "global_batch": pairs_per_step, "clips_per_step": clips_per_step, "seq_len": args.seq,
                        "parallelism": f"dp{world}", "loss_first": loss0, "loss_last": m["loss"],
-                       "step_graph": step_graph,
+                       "step_graph": step_graph, "host_ms_per_step_unblocked": round(host_free_ms, 2),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
