@@ -613,8 +613,9 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   // panel kernel (gemm_stream.hip: weight resident in LDS, every wave on its own rows, no barriers) was built for all of them and
   // MEASURED against the tiled kernels (tools/stream_bench.py, profiles/r03_stream_bench.txt): it wins only where the output is wide
   // and the epilogue is a plain bias — qkv of blocks 0-3: 1.06-1.22x — and loses everywhere else (N = C outputs 0.63-0.98x: the
-  // tiled kernels already stream those at 4.5-5.3 TB/s; two-tensor / gelu' epilogues 0.34-0.62x: a lane's 16-byte pieces cover
-  // only 32 bytes of a row per store instruction, which the non-temporal pre-activation path turns into partial-line HBM writes).
+  // tiled kernels already stream those at 4.5-5.3 TB/s; two-tensor / gelu' epilogues 0.60-0.85x: a lane pair's 16-byte pieces cover
+  // only 32 bytes of a row per store / load instruction, against the tiled kernels' LDS-transposed full 128-byte lines — and 0.34x
+  // when the saved pre-activation used the non-temporal hint, which sends such partial lines to HBM as they are).
   // So it takes exactly the shapes it wins; DCC_STREAM_GEMM=0 disables it, =2 (or variant 12: tests, tools/stream_bench.py) widens
   // it to its whole domain.
   static const int stream_mode = getenv("DCC_STREAM_GEMM") ? atoi(getenv("DCC_STREAM_GEMM")) : 1;
