@@ -282,31 +282,45 @@ __device__ __forceinline__ bf16x8 rfrag_km(const char* base, int pitch, int c0, 
 }
 
 #ifdef RB_PROF
-__device__ unsigned long long g_rbprof[8];
+__device__ unsigned long long g_rbprof[12];
 #define RBT() __builtin_amdgcn_s_memtime()
 #define RBP(i, t0) do { if (tid == 0) atomicAdd(&g_rbprof[i], RBT() - (t0)); } while (0)
 #else
 #define RBT() 0ull
 #define RBP(i, t0) do { } while (0)
 #endif
-template <int NMT>   // 32-row slabs of dR per wave: ceil(LPp / 32 / 4)
+// LN: the per-head LayerNorm backward of the pooled queries (Pool.norm_act, the op autograd runs next on dq) in the epilogue:
+// what is stored is dconv = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dq * gamma, xhat = (conv - mean) * rstd, with dq
+// rounded to bf16 first exactly as the two-kernel path stores it; the block's dgamma / dbeta partials follow its table gradient
+// in the workspace row.  Saves the dq round trip through HBM and two launches per block (ln_bwd + ln_reduce).
+struct RelLn { const bf16_t* conv; const float* mean; const float* rstd; const float* gamma; };
+template <int NMT, bool LN>   // NMT: 32-row slabs of dR per wave: ceil(LPp / 32 / 4)
 __global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(const bf16_t* __restrict__ dQf, const bf16_t* __restrict__ Qf,
                                                               bf16_t* __restrict__ dq, const bf16_t* __restrict__ Rcat,
                                                               float* __restrict__ ws, const int* __restrict__ idx_h,
                                                               const int* __restrict__ idx_w, const int* __restrict__ idx_t,
                                                               RelGeom g, RelDiv dv, float inv_scale, unsigned rows, int LPp,
-                                                              int dpp, unsigned ntiles) {
+                                                              int dpp, unsigned ntiles, RelLn ln) {
   extern __shared__ __attribute__((aligned(16))) char rlds[];
   char* Rs = rlds;                       // [LPp][192 B]   stacked tables, zero rows past g.L
   char* dP = Rs + LPp * 192;             // [64][dpp]
   char* Qs = dP + 64 * dpp;              // [64][192 B]   q rows of the tile
   constexpr int RZP = 208;               // residual tile row pitch (192 + 16: the epilogue's 8-byte reads stay conflict-light)
   char* Rz = Qs + 64 * 192;              // [64][RZP]     dQf[:, :96] rows of the tile
-  int* ih = reinterpret_cast<int*>(Rz + 64 * RZP);
+  float* lnp = reinterpret_cast<float*>(Rz + 64 * RZP);   // LN: [3][64][2]  per-wave (32-column) row sums of g and g * xhat
+  float* gml = lnp + 3 * 64 * 2;                          // LN: [96] gamma
+  int* ih = reinterpret_cast<int*>(Rz + 64 * RZP + (LN ? 3 * 64 * 8 + 96 * 4 : 0));
   int* iw = ih + g.qh * g.kh;
   int* it = iw + g.qw * g.kw;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
   const unsigned long long tp0 = RBT();
+  // LN: this lane's 16 epilogue columns are 32 * wave + 8 * g4 + 4 * h + e
+  // LN parameter gradients: after each tile a butterfly over the 32 rows a half-wave holds leaves ONE of the half-wave's 32 column
+  // sums (16 of dy * xhat, 16 of dy) in each lane; that lane accumulates it over the block's tiles
+  float pgrad = 0.0f;
+  if constexpr (LN) {
+    if (tid < 96) gml[tid] = ln.gamma[tid];
+  }
   for (int i = tid; i < LPp * 12; i += 256) {
     const int l = i / 12;
     const u32x4 z = {0u, 0u, 0u, 0u};
@@ -365,10 +379,14 @@ __global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(
     RBP(2, t2);
     const unsigned long long t3 = RBT();
     if (live && p.tok) {
+      // the column arithmetic below is tile-invariant; computed here each tile (a few VALU ops per column) rather than hoisted
+      // out of the tile loop, where it held ~35 registers across the whole kernel
+      int jb = part * apq;
+      asm volatile("" : "+v"(jb));
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         if (e >= apq) break;
-        const int j = part * apq + e;
+        const int j = jb + e;
         if (j < areal) {
           const int ax = (j >= g.kh) + (j >= g.kh + g.kw);
           const int l = ax == 0 ? ih[p.hh * g.kh + j] : (ax == 1 ? iw[p.w * g.kw + (j - g.kh)] : it[p.t * g.kt + (j - g.kh - g.kw)]);
@@ -380,6 +398,26 @@ __global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(
     }
     __syncthreads();   // dP, Qs and the residual tile are complete
     RBP(3, t3);
+    // LN: the epilogue lanes fetch their own pieces of the tile's conv rows and the rows' statistics here; both products run
+    // before the first use (fetched before the scatter they cost 18 spilled registers)
+    u32x2 cz[LN ? 2 : 1][LN ? 4 : 1];
+    float mu[2] = {0.0f, 0.0f}, rsd[2] = {0.0f, 0.0f};
+    if constexpr (LN) {
+      if (wave < 3) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned orow = tile * 64u + 32 * i + (lane & 31);
+          const bool ok = orow < rows;
+          const bf16_t* src = ln.conv + (int64_t)(ok ? orow : 0u) * g.D + 32 * wave + 4 * h;
+          const u32x2 z2 = {0u, 0u};
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) cz[i][g4] = ok ? *reinterpret_cast<const u32x2*>(src + 8 * g4) : z2;
+          mu[i] = ok ? ln.mean[orow] : 0.0f;
+          rsd[i] = ok ? ln.rstd[orow] : 0.0f;
+        }
+      }
+    }
+
     const unsigned long long t4 = RBT();
     // ---- product 2: dR[l][c] += sum_rows dP[row][l] q[row][c]   (k = the 64 tile rows)
 #pragma unroll
@@ -400,8 +438,8 @@ __global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(
     RBP(4, t4);
     const unsigned long long t5 = RBT();
     // ---- product 1: dq[row][c] = sum_l dP[row][l] Rcat[l][c] + residual   (waves 0..2: 32 columns each; C^T form, lanes = rows)
+    f32x16 acc[2];
     if (wave < 3) {
-      f32x16 acc[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -411,24 +449,101 @@ __global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[i] = mma16(fb, rfrag_kc(dP, dpp, 32 * i, s, lane), acc[i]);
       }
+      RBP(5, t5);
+      if constexpr (!LN) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const unsigned orow = tile * 64u + 32 * i + (lane & 31);
-        if (orow < rows) {
+        for (int i = 0; i < 2; ++i) {
+          const unsigned orow = tile * 64u + 32 * i + (lane & 31);
+          if (orow < rows) {
+            const char* res = Rz + (32 * i + (lane & 31)) * RZP + (32 * wave + 4 * h) * 2;
+            bf16_t* dst = dq + (int64_t)orow * g.D + 32 * wave + 4 * h;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + 16 * g4);
+              bf16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[i][4 * g4 + e] + (float)rv[e]);
+              *reinterpret_cast<bf16x4*>(dst + 8 * g4) = o;
+            }
+          }
+        }
+      } else {
+        // phase 1: dq (rounded as the two-kernel path stores it) stays in acc; row sums over this wave's 32 columns -> LDS
+        float pv[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) pv[k] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
           const char* res = Rz + (32 * i + (lane & 31)) * RZP + (32 * wave + 4 * h) * 2;
-          bf16_t* dst = dq + (int64_t)orow * g.D + 32 * wave + 4 * h;
+          float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + 16 * g4);
-            bf16x4 o;
+            const bf16x4 cv = __builtin_bit_cast(bf16x4, cz[i][g4]);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gml + 32 * wave + 8 * g4 + 4 * h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[i][4 * g4 + e] + (float)rv[e]);
-            *reinterpret_cast<bf16x4*>(dst + 8 * g4) = o;
+            for (int e = 0; e < 4; ++e) {
+              const int k = 4 * g4 + e;
+              const float d = (float)(bf16_t)(acc[i][k] + (float)rv[e]);
+              const float xh = ((float)cv[e] - mu[i]) * rsd[i];
+              const float gg = d * gm[e];
+              acc[i][k] = d;
+              s1 += gg;
+              s2 += gg * xh;
+              pv[k] += d * xh;
+              pv[16 + k] += d;
+            }
+          }
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
+          if (h == 0) *reinterpret_cast<f32x2*>(lnp + ((wave * 64) + 32 * i + (lane & 31)) * 2) = f32x2{s1, s2};
+        }
+        // reduce-scatter over the half-wave's 32 lanes: 16 + 8 + 4 + 2 + 1 exchanges; lane l ends with the sum of value l & 31
+#pragma unroll
+        for (int w = 16; w > 0; w >>= 1) {
+          const bool up = (lane & w) != 0;
+#pragma unroll
+          for (int j = 0; j < w; ++j) {
+            const float keep = up ? pv[w + j] : pv[j], send = up ? pv[j] : pv[w + j];
+            pv[j] = keep + __shfl_xor(send, w);
+          }
+        }
+        pgrad += pv[0];
+      }
+    }
+    RBP(7, t5);
+    if constexpr (LN) {
+      const unsigned long long t8 = RBT();
+      __syncthreads();   // the three column slabs' row sums are in LDS (next written after the next tile's barriers)
+      RBP(8, t8);
+      if (wave < 3) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = 32 * i + (lane & 31);
+          const unsigned orow = tile * 64u + row;
+          if (orow < rows) {
+            const f32x2 p0 = *reinterpret_cast<const f32x2*>(lnp + row * 2), p1 = *reinterpret_cast<const f32x2*>(lnp + (64 + row) * 2),
+                        p2 = *reinterpret_cast<const f32x2*>(lnp + (128 + row) * 2);
+            const float m1 = (p0[0] + p1[0] + p2[0]) / 96.0f, m2 = (p0[1] + p1[1] + p2[1]) / 96.0f;
+            bf16_t* dst = dq + (int64_t)orow * g.D + 32 * wave + 4 * h;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const bf16x4 cv = __builtin_bit_cast(bf16x4, cz[i][g4]);
+              const f32x4 gm = *reinterpret_cast<const f32x4*>(gml + 32 * wave + 8 * g4 + 4 * h);
+              bf16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int k = 4 * g4 + e;
+                const float xh = ((float)cv[e] - mu[i]) * rsd[i];
+                o[e] = (bf16_t)(rsd[i] * (acc[i][k] * gm[e] - m1 - xh * m2));
+              }
+              *reinterpret_cast<bf16x4*>(dst + 8 * g4) = o;
+            }
           }
         }
       }
     }
-    RBP(5, t5);
+    RBP(9, t5);
   };
   // NMT == 2 (the 240-row tables of block 0: one block per CU anyway): two register sets, two tiles of loads in flight
   // (349 -> 269 us).  NMT == 1: one set — the second costs 130 VGPRs and the second block per CU (stage 2: 57 -> 64 us).
@@ -443,8 +558,14 @@ __global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(
     }
   }
   const unsigned long long t6 = RBT();
-  // ---- this block's table gradient -> workspace [block][g.L][96]
-  float* out = ws + (int64_t)blockIdx.x * g.L * 96;
+  // ---- this block's table gradient -> workspace [block][g.L][96] (+ [2][96] LayerNorm parameter partials with LN)
+  float* out = ws + (int64_t)blockIdx.x * (g.L * 96 + (LN ? 192 : 0));
+  if constexpr (LN) {
+    if (wave < 3) {
+      const int k = lane & 15;   // value lane & 31: k of dgamma below 16, k of dbeta from 16
+      out[g.L * 96 + ((lane & 16) ? 96 : 0) + 32 * wave + 8 * (k >> 2) + 4 * h + (k & 3)] = pgrad;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NMT; ++i) {
     const int mt = wave + 4 * i;
@@ -566,7 +687,9 @@ __global__ __launch_bounds__(256, NNT == 1 ? 2 : 1) void relpos_fwd_mfma_kernel(
 
 // out[i] += sum_b ws[b][i]  (i over n4 float4 columns): block = 64 columns x 4 row lanes, gridDim.y row slices, the four lanes
 // fold through LDS and every slice adds its sum with one atomic per element.
-__global__ __launch_bounds__(256) void relpos_fold_kernel(const float* __restrict__ ws, float* __restrict__ out, int nb, int n4) {
+// columns [0, nr4) of a block's workspace row go to out, the next 24 to dgamma, the last 24 to dbeta (n4 = nr4 or nr4 + 48)
+__global__ __launch_bounds__(256) void relpos_fold_kernel(const float* __restrict__ ws, float* __restrict__ out, int nb, int n4, int nr4,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ f32x4 red[256];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -576,8 +699,9 @@ __global__ __launch_bounds__(256) void relpos_fold_kernel(const float* __restric
   __syncthreads();
   if (rl == 0 && c < n4) {
     s = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+    float* dst = c < nr4 ? out + 4 * c : (c < nr4 + 24 ? dgamma + 4 * (c - nr4) : dbeta + 4 * (c - nr4 - 24));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(out + 4 * c + e, s[e]);
+    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, s[e]);
   }
 }
 
@@ -668,21 +792,26 @@ extern "C" int dcc_relpos_kaug(void* Kf, const int* dims, const int64_t* strides
 // Fused backward: dq [B*Nq*H][D] = dQf[:, :D] + (dQf[:, D:] / scale) against the table rows; dRcat [L][D] fp32 is ACCUMULATED
 // into (the gradient of the three stacked tables); ws: scratch of max_blocks * L * D floats for the per-block partials (no
 // initialisation needed).  = dcc_relpos_scatter + dcc_gemm (dP Rcat + residual) + dcc_gemm (dP^T q).
-extern "C" int dcc_relpos_aug_bwd(const void* dQf, const void* Qf, void* dq, const void* Rcat, float* dRcat, float* ws,
-                                  int max_blocks, const int* idx_h, const int* idx_w, const int* idx_t, const int* dims,
-                                  const int64_t* strides, float scale, int dtype, void* stream) {
+// With ln: what is stored is the LayerNorm backward of dq (see the kernel), dgamma / dbeta [D] fp32 accumulated into, and
+// the workspace holds max_blocks * (L + 2) * D floats.
+static int relpos_bwd_launch(const void* dQf, const void* Qf, void* dq, const void* Rcat, float* dRcat, float* ws, int max_blocks,
+                             const int* idx_h, const int* idx_w, const int* idx_t, const int* dims, const int64_t* strides,
+                             float scale, int dtype, void* stream, const RelLn* lnp, float* dgamma, float* dbeta) {
   if (!dQf || !Qf || !dq || !Rcat || !dRcat || !ws || !idx_h || !idx_w || !idx_t || !dims || !strides || max_blocks < 1) return DCC_ERR_ARG;
+  if (lnp && (!lnp->conv || !lnp->mean || !lnp->rstd || !lnp->gamma || !dgamma || !dbeta)) return DCC_ERR_ARG;
   if (dtype != DCC_BF16) return DCC_ERR_UNSUPPORTED;
   RelGeom g = mk(dims, strides);
   if (g.D != 96 || (g.A != 32 && g.A != 64) || g.A < g.kh + g.kw + g.kt || g.L < g.Lh + g.Lw + g.Lt || (g.L % 8)) return DCC_ERR_UNSUPPORTED;
   if ((g.sb % 8) || (g.sn % 8) || (g.sh % 8) || (((uintptr_t)dQf) & 15) || (((uintptr_t)Qf) & 15) || (((uintptr_t)dq) & 7) ||
       (((uintptr_t)Rcat) & 15) || (((uintptr_t)ws) & 15))
     return DCC_ERR_UNSUPPORTED;
+  if (lnp && ((((uintptr_t)lnp->conv) & 7) || (((uintptr_t)dgamma) & 3) || (((uintptr_t)dbeta) & 3))) return DCC_ERR_UNSUPPORTED;
   const int64_t rows = (int64_t)g.B * (g.qt * g.qh * g.qw + g.has_cls) * g.H;
   const int LPp = (g.L + 31) & ~31;
   if (LPp > 256 || rows >= (1LL << 31)) return DCC_ERR_UNSUPPORTED;
   const int dpp = LPp * 2 + (((LPp / 8) & 1) ? 0 : 16);   // row pitch of dP: an odd number of 16-byte units
-  const size_t lds = (size_t)LPp * 192 + (size_t)64 * dpp + 64 * 192 + 64 * 208 + (size_t)(g.qh * g.kh + g.qw * g.kw + g.qt * g.kt) * 4;
+  const size_t lds = (size_t)LPp * 192 + (size_t)64 * dpp + 64 * 192 + 64 * 208 + (lnp ? 3 * 64 * 8 + 96 * 4 : 0) +
+                     (size_t)(g.qh * g.kh + g.qw * g.kw + g.qt * g.kt) * 4;
   if (lds > 150 * 1024) return DCC_ERR_UNSUPPORTED;
   const int64_t ntiles = (rows + 63) / 64;
   const int per_cu = (int)((160 * 1024) / lds);
@@ -691,30 +820,52 @@ extern "C" int dcc_relpos_aug_bwd(const void* dQf, const void* Qf, void* dq, con
   if (nb > max_blocks) nb = max_blocks;
   hipStream_t st = (hipStream_t)stream;
   const RelDiv dv{mkdiv(g.H), mkdiv(g.qt * g.qh * g.qw + g.has_cls), mkdiv(g.qw * g.qh), mkdiv(g.qw), mkdiv(1), mkdiv(1)};
-  auto k1 = relpos_bwd_mfma_kernel<1>;
-  auto k2 = relpos_bwd_mfma_kernel<2>;
+  auto k1 = relpos_bwd_mfma_kernel<1, false>;
+  auto k2 = relpos_bwd_mfma_kernel<2, false>;
+  auto k1l = relpos_bwd_mfma_kernel<1, true>;
+  auto k2l = relpos_bwd_mfma_kernel<2, true>;
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-      return DCC_ERR_LAUNCH;
+    for (const void* f : {reinterpret_cast<const void*>(k1), reinterpret_cast<const void*>(k2), reinterpret_cast<const void*>(k1l),
+                          reinterpret_cast<const void*>(k2l)})
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return DCC_ERR_LAUNCH;
     configured = true;
   }
-  if (LPp <= 128) hipLaunchKernelGGL(k1, dim3((unsigned)nb), dim3(256), lds, st, (const bf16_t*)dQf, (const bf16_t*)Qf, (bf16_t*)dq, (const bf16_t*)Rcat, ws, idx_h, idx_w, idx_t, g, dv, 1.0f / scale, (unsigned)rows, LPp, dpp, (unsigned)ntiles);
-  else hipLaunchKernelGGL(k2, dim3((unsigned)nb), dim3(256), lds, st, (const bf16_t*)dQf, (const bf16_t*)Qf, (bf16_t*)dq, (const bf16_t*)Rcat, ws, idx_h, idx_w, idx_t, g, dv, 1.0f / scale, (unsigned)rows, LPp, dpp, (unsigned)ntiles);
+  const RelLn ln = lnp ? *lnp : RelLn{nullptr, nullptr, nullptr, nullptr};
+  auto kern = lnp ? (LPp <= 128 ? k1l : k2l) : (LPp <= 128 ? k1 : k2);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, (const bf16_t*)dQf, (const bf16_t*)Qf, (bf16_t*)dq, (const bf16_t*)Rcat, ws,
+                     idx_h, idx_w, idx_t, g, dv, 1.0f / scale, (unsigned)rows, LPp, dpp, (unsigned)ntiles, ln);
   int rc = dcc_check_launch();
   if (rc) return rc;
-  const int n4 = g.L * 24;
-  hipLaunchKernelGGL(relpos_fold_kernel, dim3((n4 + 63) / 64, 8), dim3(256), 0, st, ws, dRcat, (int)nb, n4);
+  const int nr4 = g.L * 24, n4 = nr4 + (lnp ? 48 : 0);
+  hipLaunchKernelGGL(relpos_fold_kernel, dim3((n4 + 63) / 64, 8), dim3(256), 0, st, ws, dRcat, (int)nb, n4, nr4, dgamma, dbeta);
   return dcc_check_launch();
 }
 
+extern "C" int dcc_relpos_aug_bwd(const void* dQf, const void* Qf, void* dq, const void* Rcat, float* dRcat, float* ws,
+                                  int max_blocks, const int* idx_h, const int* idx_w, const int* idx_t, const int* dims,
+                                  const int64_t* strides, float scale, int dtype, void* stream) {
+  return relpos_bwd_launch(dQf, Qf, dq, Rcat, dRcat, ws, max_blocks, idx_h, idx_w, idx_t, dims, strides, scale, dtype, stream, nullptr,
+                           nullptr, nullptr);
+}
+
+// dcc_relpos_aug_bwd followed by dcc_layernorm_bwd of its result against the pooled queries (conv [B*Nq*H][D] bf16 contiguous,
+// mean / rstd [B*Nq*H], gamma [D]) in one kernel: dconv replaces dq, dgamma / dbeta are accumulated into.
+extern "C" int dcc_relpos_aug_bwd_ln(const void* dQf, const void* Qf, void* dconv, const void* Rcat, float* dRcat, float* ws,
+                                     int max_blocks, const int* idx_h, const int* idx_w, const int* idx_t, const int* dims,
+                                     const int64_t* strides, float scale, const void* conv, const float* mean, const float* rstd,
+                                     const float* gamma, float* dgamma, float* dbeta, int dtype, void* stream) {
+  const RelLn ln{(const bf16_t*)conv, mean, rstd, gamma};
+  return relpos_bwd_launch(dQf, Qf, dconv, Rcat, dRcat, ws, max_blocks, idx_h, idx_w, idx_t, dims, strides, scale, dtype, stream, &ln,
+                           dgamma, dbeta);
+}
+
 #ifdef RB_PROF
-extern "C" int dcc_relpos_prof_read(unsigned long long* out8, int reset) {
-  unsigned long long h[8];
+extern "C" int dcc_relpos_prof_read(unsigned long long* out12, int reset) {
+  unsigned long long h[12];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rbprof), sizeof(h)) != hipSuccess) return DCC_ERR_LAUNCH;
-  for (int i = 0; i < 8; ++i) out8[i] = h[i];
-  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rbprof), z, sizeof(z)) != hipSuccess) return DCC_ERR_LAUNCH; }
+  for (int i = 0; i < 12; ++i) out12[i] = h[i];
+  if (reset) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rbprof), z, sizeof(z)) != hipSuccess) return DCC_ERR_LAUNCH; }
   return DCC_OK;
 }
 #endif

@@ -602,6 +602,9 @@ FUSED_KV_PAIR = os.environ.get("DCC_FUSED_KV_PAIR", "1") != "0"   # k and v pool
 FUSED_RELPOS = os.environ.get("DCC_FUSED_RELPOS", "1") != "0"
 # rel-pos backward as one MFMA kernel that builds dP per 64-row tile in LDS (dcc_relpos_aug_bwd) instead of scatter + two GEMMs
 FUSED_RELPOS_BWD = os.environ.get("DCC_FUSED_RELPOS_BWD", "1") != "0"
+# ... with the query pool's LayerNorm backward in its epilogue (dcc_relpos_aug_bwd_ln; without RoPE, whose inverse rotation sits
+# between the two); DCC_FUSED_RELPOS_LN=0 keeps rel-pos backward + layernorm_bwd as separate launches
+FUSED_RELPOS_LN = os.environ.get("DCC_FUSED_RELPOS_LN", "0") != "0"
 # depthwise-conv weight gradients of the q/k/v pools on the parameter-gradient side stream (joined at the end of backward)
 POOL_WGRAD_SIDE = os.environ.get("DCC_POOL_WGRAD_SIDE", "1") != "0"
 PARAM_SIDE_OK = False   # set by the runner around backward: one rank, no accumulation, no gradient hooks that would read early
@@ -721,17 +724,19 @@ class MvitAttnCoreFn(torch.autograd.Function):
         qkv5 = qkv.view(B, N, 3, H, D)
         ctx.pool_w_unset = [grads_unset(p_) for p_ in ctx.pool_params]
 
-        def pool_branch(name, i, dy4, conv, mean, rstd, gam, w):
-            """LayerNorm backward -> pool data gradient + pool weight gradient of one of the q / k / v branches."""
+        def pool_branch(name, i, dy4, conv, mean, rstd, gam, w, dconv=None):
+            """LayerNorm backward -> pool data gradient + pool weight gradient of one of the q / k / v branches
+            (dconv given: the LayerNorm backward already happened in the producer of dy)."""
             g = geo[name]
             rows = B * g.n_out * H
-            if dy4.is_contiguous():
-                dy2 = dy4.view(rows, D)
-            else:  # dk is a column slice of the [.., DQK] buffer: rows are strided by DQK
-                dy2 = dy4.as_strided((rows, D), (dy4.stride(2), 1), dy4.storage_offset())
             dgam, dbet = small[i, 0], small[i, 1]
             dw = small_w[i]
-            dconv = K.layernorm_bwd(dy2, conv.view(rows, D), mean, rstd, gam, dgam, dbet)
+            if dconv is None:
+                if dy4.is_contiguous():
+                    dy2 = dy4.view(rows, D)
+                else:  # dk is a column slice of the [.., DQK] buffer: rows are strided by DQK
+                    dy2 = dy4.as_strided((rows, D), (dy4.stride(2), 1), dy4.storage_offset())
+                dconv = K.layernorm_bwd(dy2, conv.view(rows, D), mean, rstd, gam, dgam, dbet)
             dconv4 = dconv.view(B, g.n_out, H, D)
             K.pool_bwd_data(dconv4, dqkv[:, :, i], g, w.reshape(D, 27))
             # the conv weight gradient feeds nothing but the optimizer: off the data path when autograd will adopt the buffer
@@ -758,11 +763,18 @@ class MvitAttnCoreFn(torch.autograd.Function):
         dims_q = K.relpos_dims(B, H, D, A, Lp, geo["q"].out_thw, geo["k"].out_thw, lens)
         rows_q = B * Nq * H
         dq = None
+        dconv_q = None
         # dP built and consumed in LDS (no [rows, L] tensor): faster than scatter + two GEMMs at every block geometry
         # (tools/relpos_bench.py: 584 -> 271 us in block 0, 71 -> 43 us in the stage-2 blocks)
         if FUSED_RELPOS_BWD and dt == torch.bfloat16 and D == 96:
             drel_cat = zeros_f32((Lp, D), dev)
-            dq = K.relpos_aug_bwd(dQf, Qf, Rcat, cfg["idx"], dims_q, scale, drel_cat)
+            # tools/relpos_bench.py (32 clips): blk1 150 -> 137 us, blk2 134 -> 116, blk3 84 -> 68, stage 2 75 -> 60, blk14 57 -> 45,
+            # blk15 52 -> 48; block 0 (240 table rows: one workgroup per CU, the epilogue's VALU work is exposed) 360 -> 376: not there
+            if FUSED_RELPOS_LN and rope is None and cq.is_contiguous() and Lp <= 128:
+                dq = dconv_q = K.relpos_aug_bwd(dQf, Qf, Rcat, cfg["idx"], dims_q, scale, drel_cat,
+                                                ln=(cq, mq, rq, gq, small[0, 0], small[0, 1]))
+            else:
+                dq = K.relpos_aug_bwd(dQf, Qf, Rcat, cfg["idx"], dims_q, scale, drel_cat)
         if dq is None:
             dP = torch.empty((rows_q, Lp), device=dev, dtype=dt)
             K.relpos_scatter(dQf, dP, cfg["inv"], dims_q, scale)
@@ -773,7 +785,7 @@ class MvitAttnCoreFn(torch.autograd.Function):
         drel = (drel_cat[:lens[0]], drel_cat[lens[0]:lens[0] + lens[1]], drel_cat[lens[0] + lens[1]:sum(lens)])
         if rope is not None:
             K.rope(dq, dq, rope["cos_q"], rope["sin_q"], backward=True)
-        pool_branch("q", 0, dq, cq, mq, rq, gq, wq)
+        pool_branch("q", 0, dq, cq, mq, rq, gq, wq, dconv=dconv_q)
         br.join()
         return (dqkv.view(B * N, 3 * H * D), grads["q"][0], grads["k"][0], grads["v"][0], grads["q"][1], grads["q"][2],
                 grads["k"][1], grads["k"][2], grads["v"][1], grads["v"][2], drel[0], drel[1], drel[2], None)

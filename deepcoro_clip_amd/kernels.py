@@ -481,22 +481,36 @@ _RELPOS_WS: dict = {}
 _RELPOS_MAX_BLOCKS = 768
 
 
-def relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dRcat):
+def relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dRcat, ln=None):
     """dq [B, Nq, H, D] = dQf[..., :D] + table path of dQf[..., D:]; dRcat [L, D] fp32 accumulated into.  None when the shape
-    is outside the fused kernel's domain (the caller then runs scatter + the two GEMMs)."""
+    is outside the fused kernel's domain (the caller then runs scatter + the two GEMMs).
+
+    ln = (conv [B, Nq, H, D], mean, rstd, gamma, dgamma, dbeta): the LayerNorm backward autograd runs next on dq (Pool.norm_act
+    of the pooled queries) happens in the kernel's epilogue and the returned tensor is dconv; dgamma / dbeta accumulated into."""
     L.require_cuda(dQf, Qf, Rcat, dRcat)
     assert Rcat.is_contiguous() and dQf.stride() == Qf.stride() and dRcat.dtype == torch.float32 and dRcat.is_contiguous()
     B, Nq, H, _ = dQf.shape
     D = Rcat.shape[1]
     dq = torch.empty((B, Nq, H, D), device=dQf.device, dtype=dQf.dtype)
-    n = _RELPOS_MAX_BLOCKS * Rcat.shape[0] * D
+    n = _RELPOS_MAX_BLOCKS * (Rcat.shape[0] + 2) * D
     key = (dQf.device.index, n, L.stream())
     ws = _RELPOS_WS.get(key)
     if ws is None:
         ws = _RELPOS_WS[key] = torch.empty(n, device=dQf.device, dtype=torch.float32)
-    ok = L.try_call("dcc_relpos_aug_bwd", L.ptr(dQf), L.ptr(Qf), L.ptr(dq), L.ptr(Rcat), L.ptr(dRcat), L.ptr(ws),
-                    _RELPOS_MAX_BLOCKS, L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims, _i64(_strides3(dQf)), float(scale),
-                    L.dt(dQf), L.stream())
+    if ln is None:
+        ok = L.try_call("dcc_relpos_aug_bwd", L.ptr(dQf), L.ptr(Qf), L.ptr(dq), L.ptr(Rcat), L.ptr(dRcat), L.ptr(ws),
+                        _RELPOS_MAX_BLOCKS, L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims, _i64(_strides3(dQf)), float(scale),
+                        L.dt(dQf), L.stream())
+    else:
+        conv, mean, rstd, gamma, dgamma, dbeta = ln
+        L.require_cuda(conv, mean, rstd, gamma, dgamma, dbeta)
+        rows = B * Nq * H
+        assert conv.is_contiguous() and conv.numel() == rows * D and conv.dtype == dQf.dtype
+        assert mean.numel() == rows and rstd.numel() == rows and mean.dtype == rstd.dtype == torch.float32
+        assert all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == D for t in (gamma, dgamma, dbeta))
+        ok = L.try_call("dcc_relpos_aug_bwd_ln", L.ptr(dQf), L.ptr(Qf), L.ptr(dq), L.ptr(Rcat), L.ptr(dRcat), L.ptr(ws),
+                        _RELPOS_MAX_BLOCKS, L.ptr(idx[0]), L.ptr(idx[1]), L.ptr(idx[2]), dims, _i64(_strides3(dQf)), float(scale),
+                        L.ptr(conv), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dgamma), L.ptr(dbeta), L.dt(dQf), L.stream())
     return dq if ok else None
 
 

@@ -119,6 +119,15 @@ int dcc_relpos_aug_fwd_mfma(void* Qf, const void* Rcat, const int* idx_h, const 
 int dcc_relpos_aug_bwd(const void* dQf, const void* Qf, void* dq, const void* Rcat, float* dRcat, float* ws, int max_blocks,
                        const int* idx_h, const int* idx_w, const int* idx_t, const int* dims, const int64_t* strides,
                        float scale, int dtype, void* stream);
+/* dcc_relpos_aug_bwd + the dcc_layernorm_bwd autograd runs next on its result (Pool.norm_act of the pooled queries,
+ * torchvision MultiscaleAttention.pool_q as called from models/video_encoder.py:232-253) in one kernel: conv [B*Nq*H][D] bf16 is
+ * the LayerNorm's input, mean / rstd [B*Nq*H] its saved statistics, gamma [D] its weight; dconv [B*Nq*H][D] is stored instead of
+ * dq (dq itself is rounded to bf16 before use, exactly as the two-kernel path stores it), dgamma / dbeta [D] fp32 are
+ * accumulated into.  ws: fp32 scratch [max_blocks * (L + 2) * D]. */
+int dcc_relpos_aug_bwd_ln(const void* dQf, const void* Qf, void* dconv, const void* Rcat, float* dRcat, float* ws, int max_blocks,
+                          const int* idx_h, const int* idx_w, const int* idx_t, const int* dims, const int64_t* strides,
+                          float scale, const void* conv, const float* mean, const float* rstd, const float* gamma, float* dgamma,
+                          float* dbeta, int dtype, void* stream);
 
 /* ---- LayerNorm (csrc/norm.hip): nn.LayerNorm in MViT blocks / Pool.norm_act / BERT / aggregator /
  * attention pool (models/video_aggregator.py:15,24,99; models/attention_pool.py:53,94). */

@@ -156,3 +156,63 @@ def test_mfma_relpos_forward_is_bit_identical_to_gemm_plus_gather(B, H, q_thw, k
     P = K.gemm(Qb.view(-1, DQK)[:, :D], Rcat)
     K.relpos_gather(Qb, P, idx, dims, scale)
     assert torch.equal(Qa, Qb)
+
+
+@pytest.mark.parametrize("B,H,q_thw,k_thw", [(2, 4, (8, 14, 14), (8, 7, 7)), (1, 2, (8, 28, 28), (8, 14, 14)),
+                                             (3, 8, (8, 7, 7), (8, 14, 14)), (1, 1, (8, 56, 56), (8, 7, 7)),
+                                             (2, 8, (8, 7, 7), (8, 7, 7)), (1, 4, (4, 14, 14), (4, 14, 14))])
+def test_fused_relpos_backward_with_layernorm_epilogue(B, H, q_thw, k_thw):
+    """dcc_relpos_aug_bwd_ln against dcc_relpos_aug_bwd followed by dcc_layernorm_bwd on the same inputs: the epilogue rounds dq
+    to bf16 before use, so dconv may differ only by the summation order of the two row means (<= 1 bf16 step), dgamma / dbeta and
+    the table gradient by fp32 summation order; and against an fp64 LayerNorm backward of the two-kernel dq."""
+    from deepcoro_clip_amd import functional as Fn
+    from deepcoro_clip_amd import kernels as K
+
+    D = 96
+    g = torch.Generator().manual_seed(11)
+    A = Fn.relpos_aug_width(k_thw)
+    DQK = D + A
+    Nq = q_thw[0] * q_thw[1] * q_thw[2] + 1
+    idx, inv, tabs = _tables(q_thw, k_thw, D, g)
+    lens = tuple(t.shape[0] for t in tabs)
+    Lp = 8 * ((sum(lens) + 7) // 8)
+    Rcat = torch.zeros(Lp, D, dtype=torch.bfloat16)
+    Rcat[:sum(lens)] = torch.cat(tabs, 0)
+    Rcat = Rcat.cuda()
+    scale = 1.0 / D ** 0.5
+    dims = K.relpos_dims(B, H, D, A, Lp, q_thw, k_thw, lens)
+    rows = B * Nq * H
+    Qf = (torch.randn(B, Nq, H, DQK, generator=g) * 0.5).bfloat16().cuda()
+    dQf = (torch.randn(B, Nq, H, DQK, generator=g) * 0.5).bfloat16().cuda()
+    conv = (torch.randn(B, Nq, H, D, generator=g) * 1.5 + 0.3).bfloat16().cuda()
+    gamma = (1.0 + 0.2 * torch.randn(D, generator=g)).cuda()
+    beta = torch.zeros(D).cuda()
+    _, mean, rstd = K.layernorm_fwd(conv.view(rows, D), gamma, beta, 1e-6)
+    # two kernels
+    dR0 = torch.zeros(Lp, D, device="cuda")
+    dq = K.relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dR0)
+    dg0, db0 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dconv0 = K.layernorm_bwd(dq.view(rows, D), conv.view(rows, D), mean, rstd, gamma, dg0, db0)
+    # one kernel; dgamma / dbeta / dR are accumulated into: start them off non-zero
+    dR1 = torch.full((Lp, D), 0.5, device="cuda")
+    dg1, db1 = torch.full((D,), 2.0, device="cuda"), torch.full((D,), -3.0, device="cuda")
+    dconv1 = K.relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dR1, ln=(conv, mean, rstd, gamma, dg1, db1))
+    assert dconv1 is not None and dconv1.shape == (B, Nq, H, D)
+    torch.cuda.synchronize()
+    a, b = dconv1.view(rows, D).float(), dconv0.float()
+    # one bf16 step at the value's binade (upper bound), plus fp32 summation-order noise of the terms that cancel into it
+    step = b.abs() * 2.0 ** -7 + 1e-6 * b.abs().max()
+    bad = (a - b).abs() > step
+    assert not bad.any(), (int(bad.sum()), (a - b).abs().max().item(), a[bad][:4].tolist(), b[bad][:4].tolist())
+    assert (a != b).float().mean().item() < 2e-2                # and nearly all elements identical
+    rel = lambda x, y: (x - y).abs().max().item() / y.abs().max().item()
+    assert rel(dg1 - 2.0, dg0) < 1e-4 and rel(db1 + 3.0, db0) < 1e-4
+    assert rel(dR1 - 0.5, dR0) < 1e-5
+    # fp64 LayerNorm backward of the bf16 dq
+    d = dq.view(rows, D).double()
+    x = conv.view(rows, D).double()
+    xh = (x - mean.double()[:, None]) * rstd.double()[:, None]
+    gg = d * gamma.double()
+    ref = rstd.double()[:, None] * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True))
+    assert rel(a.double(), ref) < 6e-3
+    assert rel((dg1 - 2.0).double(), (d * xh).sum(0)) < 1e-4 and rel((db1 + 3.0).double(), d.sum(0)) < 1e-4

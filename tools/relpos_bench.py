@@ -61,8 +61,20 @@ def main():
         dR = torch.zeros(Lp, D, device="cuda")
         fb = K.relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dR)
         fusedb = f"{t(lambda: K.relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dR)):7.1f} us" if fb is not None else "   n/a"
+        # the query pool's LayerNorm backward: as the next launch pair (ln_bwd + ln_reduce) or in the rel-pos kernel's epilogue
+        conv = torch.randn(B, Nq, H, D, device="cuda").bfloat16()
+        gamma = torch.ones(D, device="cuda"); beta = torch.zeros(D, device="cuda")
+        _, mean, rstd = K.layernorm_fwd(conv.view(rows, D), gamma, beta, 1e-6)
+        dg = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
+        lnb = ""
+        if fb is not None:
+            def two():
+                dq = K.relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dR)
+                K.layernorm_bwd(dq.view(rows, D), conv.view(rows, D), mean, rstd, gamma, dg, db)
+            one = lambda: K.relpos_aug_bwd(dQf, Qf, Rcat, idx, dims, scale, dR, ln=(conv, mean, rstd, gamma, dg, db))
+            lnb = f";  bwd + q-pool LayerNorm bwd: separate {t(two):7.1f} us, epilogue {t(one):7.1f} us"
         print(f"{name}: rows {rows}, L {Lp}, A {A}:  fwd gemm+gather {t(old_f):7.1f} us, {fused};"
-              f"  bwd scatter+2 gemm {t(old_b):7.1f} us, fused (MFMA) {fusedb}", flush=True)
+              f"  bwd scatter+2 gemm {t(old_b):7.1f} us, fused (MFMA) {fusedb}{lnb}", flush=True)
 
 
 if __name__ == "__main__":
