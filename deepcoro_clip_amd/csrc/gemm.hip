@@ -605,6 +605,10 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   // persistent LDS-DMA ring kernel: the towers' large GEMMs, and (measured in round 1) also the small grids
   // of the text tower and the deep-K rel-pos table gradients, where its 3-4 stage pipeline hides the per-step load
   // latency the tiled kernel exposes (variant 6 restores the tiled kernel for small grids)
+  if (in_dtype == DCC_BF16 && out_dtype == DCC_BF16 && aligned && variant == 13 && !a_km && !b_km) {  // experimental eight-phase kernel
+    const int rc = dcc_gemm_p8_launch(p, st);
+    if (rc != DCC_ERR_UNSUPPORTED) return rc;
+  }
   if (in_dtype == DCC_BF16 && aligned && (variant == 8 || variant == 9 || variant == 11)) {  // A/B knob: force the wide-tile kernel
     const int rc = dcc_gemm_wide_launch(p, a_km, b_km, out_dtype, variant == 8 ? 256 : 128, variant == 11 ? 3 : 4, st);
     if (rc != DCC_ERR_UNSUPPORTED) return rc;
