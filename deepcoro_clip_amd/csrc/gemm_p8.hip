@@ -37,7 +37,7 @@ constexpr int KT_B = 4 * PIECE_B;           // one K-tile: S0 S1 S2 S3
 constexpr int PBIAS_OFF = 2 * KT_B;         // two 1-KB bias slots (item parity)
 constexpr int P8_LDS = PBIAS_OFF + 2 * 1024;
 
-struct P8Geo { int items, tilesN, nk, dbg; };   // dbg (DCC_P8_DEBUG, experiments): 1 = no stores, 2 = no epilogue
+struct P8Geo { int items, tilesN, nk, dbg, stagger; };   // stagger: 2048-cycle sleeps before the first tile of a workgroup that has one item fewer   // dbg (DCC_P8_DEBUG, experiments): 1 = no stores, 2 = no epilogue
 
 template <int N> __device__ __forceinline__ void pwait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void pwait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -71,6 +71,12 @@ __global__ __launch_bounds__(PNT, 1) void gemm_p8_kernel(GemmParams p, P8Geo geo
   int nitems = 0;
   for (int i = item0; i < geo.items; i += G) ++nitems;
   if (nitems == 0) return;
+  // Tile boundaries of the persistent workgroups coincide (same K, same start): every round ends in a chip-wide store burst that
+  // the next K-tile's counted wait has to sit out.  The workgroups with one item fewer have a tile's worth of slack: they start late.
+  if (geo.stagger > 0 && (geo.items % G) && item0 >= geo.items % G) {   // floor(items / G) items here, ceil elsewhere
+    const int n = geo.stagger / 2 + ((bid >> 3) & 1) * (geo.stagger / 2);   // two start times among them
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+  }
   const int nk = geo.nk;
   const int TT = nitems * nk;   // K-tiles of this workgroup
   const int NP = 4 * TT;        // pieces
@@ -338,6 +344,9 @@ int dcc_gemm_p8_launch(const GemmParams& p, hipStream_t st) {
   geo.nk = p.K / 64;
   static const int dbg = getenv("DCC_P8_DEBUG") ? atoi(getenv("DCC_P8_DEBUG")) : 0;
   geo.dbg = dbg;
+  // DCC_P8_STAGGER (experiment): start delay of the lighter workgroups in per-mille of a tile's time (~ nk * 3300 + 6000 cycles)
+  static const int stag = getenv("DCC_P8_STAGGER") ? atoi(getenv("DCC_P8_STAGGER")) : 0;
+  geo.stagger = (int)((int64_t)stag * (geo.nk * 3300 + 6000) / 1000 / 2048);
   const int ef = p.flags & (GEMM_BIAS | GEMM_GELU | GEMM_SAVE_PRE | GEMM_RESID | GEMM_DGELU);
   void (*kern)(GemmParams, P8Geo) = gemm_p8_kernel<-1>;
   if (ef == 0) kern = gemm_p8_kernel<0>;
