@@ -640,9 +640,12 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
       !(flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && M >= 8192 && K >= 128) {
     int bn = 0, ns = 4;
     if (!b_km && N >= 1024 && K <= 768) {
-      // one output tensor (qkv): 256 x 128 tiles, two workgroups per CU, 66 us against 74 (256 x 256) and 78 (ring) at
-      // M 50208 N 1152 K 384; fc1 (pre-activation + GELU: two stores) stays on 256 x 256 (141 against 148)
-      if (flags & GEMM_SAVE_PRE) bn = 256; else { bn = 128; ns = 3; }
+      // 256 x 128 tiles, two workgroups per CU (one's epilogue under the other's main loop): qkv 61.5 us against 68.5 (256 x 256) and
+      // 72.8 (ring) at M 50208 N 1152 K 384; fc1 (pre-activation + GELU: two stores) 98.7 against 104.6 / 119.8, and 85.7 against
+      // 95.2 / 100.3 at stage 3 (M 12576 N 3072 K 768) — tools/p8_bench.py, variants interleaved in one process
+      // (profiles/r03_p8_bench.txt; round 2 had measured fc1 in sequential blocks per variant and kept it on 256 x 256)
+      bn = 128; ns = 3;
+      if (wide_mode == 5 && (flags & GEMM_SAVE_PRE)) { bn = 256; ns = 4; }   // A/B: the round-2 choice for fc1
     }
     if (b_km && (flags & GEMM_DGELU) && N >= 1024 && K <= 768 && wide_mode != 4) { bn = 128; ns = 3; }  // 147 us against 156 (ring)
     if (wide_mode == 4 && !b_km && N >= 1024 && K <= 768) { bn = 256; ns = 4; }   // A/B: the round-2 choice

@@ -6,7 +6,7 @@ from deepcoro_clip_amd import kernels as K
 
 
 def t(fn, reps=20):
-    for _ in range(3): fn()
+    for _ in range(2): fn()
     torch.cuda.synchronize()
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     s.record()
@@ -19,18 +19,37 @@ def main():
     shapes = [("plain", 50208, 1536, 384, {}), ("qkv bias", 50208, 1152, 384, {"bias": 1}), ("fc1 bias+gelu+pre", 50208, 1536, 384, {"bias": 1, "gelu": 1}),
               ("fc2 bias+resid", 50208, 384, 1536, {"bias": 1, "resid": 1}), ("plain", 50208, 384, 1536, {}), ("plain", 50208, 384, 384, {}),
               ("cube", 4096, 4096, 4096, {}), ("cube", 8192, 8192, 8192, {})]
+    if len(sys.argv) > 1 and sys.argv[1] == "fc1":   # the fc1-forward shapes of stages 2 and 3 (dispatch choice between the wide kernels)
+        shapes = [("fc1 bias+gelu+pre", 50208, 1536, 384, {"bias": 1, "gelu": 1}), ("fc1 bias+gelu+pre", 12576, 3072, 768, {"bias": 1, "gelu": 1}),
+                  ("qkv bias", 12576, 2304, 768, {"bias": 1})]
+    if len(sys.argv) > 1 and sys.argv[1] == "n384":   # the N = C products of a stage-2 block, forward and data gradients (k-major weight)
+        shapes = [("proj bias+resid", 50208, 384, 384, {"bias": 1, "resid": 1}), ("dx proj (NT)", 50208, 384, 384, {"b_km": 1}),
+                  ("dx fc1 (NT)", 50208, 384, 1536, {"b_km": 1}), ("dx qkv (NT)", 50208, 384, 1152, {"b_km": 1}),
+                  ("dpre dgelu (NT)", 50208, 1536, 384, {"b_km": 1, "dgelu": 1}), ("dpre dgelu (NN)", 50208, 1536, 384, {"dgelu": 1}),
+                  ("dx fc1 (NN)", 50208, 384, 1536, {}), ("dx qkv (NN)", 50208, 384, 1152, {})]
+    if len(sys.argv) > 2 and sys.argv[2] == "nn": shapes = shapes[-4:]
     for name, M, N, Kd, ep in shapes:
         a = (torch.rand(M, Kd, device="cuda") * 2 - 1).bfloat16()
         b = ((torch.rand(N, Kd, device="cuda") * 2 - 1) * (0.05 if ep else 1.0)).bfloat16()
+        if ep.get("b_km"): b = b.t().contiguous()   # [K, N]: B(n, k) k-major
         c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         kw = {}
         if ep.get("bias"): kw["bias"] = torch.randn(N, device="cuda")
         if ep.get("resid"): kw["resid"] = torch.randn(M, N, device="cuda").bfloat16()
         if ep.get("gelu"): kw.update(gelu=True, save_pre=True, aux=torch.empty(M, N, device="cuda", dtype=torch.bfloat16))
+        if ep.get("dgelu"): kw.update(dgelu=True, aux=torch.randn(M, N, device="cuda").bfloat16())
+        if ep.get("b_km"): kw["b_km"] = True
+        # interleaved rounds (one process, variants alternate): a variant measured first after an idle gap runs at a higher clock than one
+        # measured after 100 launches at the power limit, so sequential blocks per variant favour the first
+        variants = (0, 10, 8, 11, 13)
+        samples = {v: [] for v in variants}
+        for rnd in range(7):
+            for v in variants:
+                K.GEMM_VARIANT = v << 8
+                samples[v].append(t(lambda: K.gemm(a, b, out=c, **kw), reps=6))
         row = []
-        for v in (0, 10, 8, 11, 13):
-            K.GEMM_VARIANT = v << 8
-            us = t(lambda: K.gemm(a, b, out=c, **kw))
+        for v in variants:
+            us = sorted(samples[v][1:])[len(samples[v][1:]) // 2]   # median of rounds 2..7
             row.append(f"v{v} {us:7.1f} us {2 * M * N * Kd / us / 1e6:7.1f} TF")
         K.GEMM_VARIANT = 0
         print(f"{name:18s} M{M} N{N} K{Kd}: " + " | ".join(row), flush=True)
