@@ -647,7 +647,7 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
       bn = 128; ns = 3;
       if (wide_mode == 5 && (flags & GEMM_SAVE_PRE)) { bn = 256; ns = 4; }   // A/B: the round-2 choice for fc1
     }
-    if (b_km && (flags & GEMM_DGELU) && N >= 1024 && K <= 768 && wide_mode != 4) { bn = 128; ns = 3; }  // 147 us against 156 (ring)
+    if (b_km && (flags & GEMM_DGELU) && N >= 768 && K <= 768 && wide_mode != 4) { bn = 128; ns = 3; }  // 134 us against 149 (ring) at stage 2, 206 against 230 at stage 1 (N 768 K 192)
     if (wide_mode == 4 && !b_km && N >= 1024 && K <= 768) { bn = 256; ns = 4; }   // A/B: the round-2 choice
     if (wide_mode >= 1 && wide_mode <= 3 && b_km && N >= 1024 && K <= 768) { bn = 256; ns = 4; }  // dgelu / NT with a wide output
     if (wide_mode >= 2 && wide_mode <= 3 && N >= 256 && N < 1024) { bn = (N % 256 == 0) ? 256 : 128; ns = 4; }  // N = C outputs

@@ -28,6 +28,12 @@ def main():
                   ("dpre dgelu (NT)", 50208, 1536, 384, {"b_km": 1, "dgelu": 1}), ("dpre dgelu (NN)", 50208, 1536, 384, {"dgelu": 1}),
                   ("dx fc1 (NN)", 50208, 384, 1536, {}), ("dx qkv (NN)", 50208, 384, 1152, {})]
     if len(sys.argv) > 2 and sys.argv[2] == "nn": shapes = shapes[-4:]
+    if len(sys.argv) > 1 and sys.argv[1] == "s13":   # stage 1 (blocks 1-2, C = 192) and stage 3 (blocks 14-15, C = 768)
+        shapes = [("s1 fc1 gelu+pre", 200736, 768, 192, {"bias": 1, "gelu": 1}), ("s1 fc2 bias+resid", 200736, 192, 768, {"bias": 1, "resid": 1}),
+                  ("s1 dpre dgelu NT", 200736, 768, 192, {"b_km": 1, "dgelu": 1}), ("s1 dx fc1 NT", 200736, 192, 768, {"b_km": 1}),
+                  ("s3 fc2 bias+resid", 12576, 768, 3072, {"bias": 1, "resid": 1}), ("s3 proj bias+resid", 12576, 768, 768, {"bias": 1, "resid": 1}),
+                  ("s3 dpre dgelu NT", 12576, 3072, 768, {"b_km": 1, "dgelu": 1}), ("s3 dx fc1 NT", 12576, 768, 3072, {"b_km": 1}),
+                  ("s3 dx qkv NT", 12576, 768, 2304, {"b_km": 1})]
     for name, M, N, Kd, ep in shapes:
         a = (torch.rand(M, Kd, device="cuda") * 2 - 1).bfloat16()
         b = ((torch.rand(N, Kd, device="cuda") * 2 - 1) * (0.05 if ep else 1.0)).bfloat16()
