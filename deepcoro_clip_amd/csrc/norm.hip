@@ -358,9 +358,14 @@ int ln_bwd_t(const void* dy, int64_t lddy, const void* x, int64_t ldx, const flo
   // atomics (256 bytes per wave-instruction) instead of storing it for ln_reduce_kernel
   static const bool ln_atomic = getenv("DCC_LN_ATOMIC") && atoi(getenv("DCC_LN_ATOMIC")) != 0;
   if (ln_atomic) ws = nullptr;
-  static const int lnb_u = getenv("DCC_LNB_U") ? atoi(getenv("DCC_LNB_U")) : 2;
+  // r03: 4 row groups in flight for one-chunk-per-lane rows (C <= 512; 170 VGPRs, three waves per SIMD) — in the step 41.47 vs 41.77 ms
+  // and 40.97 vs 41.11 ms against 2 on two boxes (alternating runs); 8 (256 VGPRs) is no better
+  static const int lnb_u = getenv("DCC_LNB_U") ? atoi(getenv("DCC_LNB_U")) : 4;
 #define LN_BU(LP, IT, UU) hipLaunchKernelGGL((ln_bwd_kernel<T, TD, LP, IT, UU>), dim3(nb = lnb_grid(rows, 64 / LP * UU, ws ? ws_cap : lnb_cap)), dim3(256), 2 * C * sizeof(float), st, dyp, lddy, xp, ldx, mean, rstd, g, dxp, lddx, dgamma, dbeta, rows, C, drp, ws)
-#define LN_B(LP, IT) do { if (lnb_u == 4 && IT == 1) LN_BU(LP, IT, 4); else if (lnb_u >= 2 && IT <= 2) LN_BU(LP, IT, 2); else LN_BU(LP, IT, 1); } while (0)
+  // U = row groups a wave keeps in flight per iteration (only the combinations used are instantiated)
+#define LN_B(LP, IT) do { if (lnb_u >= 8 && IT == 1 && LP <= 32) LN_BU(LP, IT, ((IT == 1 && LP <= 32) ? 8 : 1)); \
+                          else if (lnb_u >= 4 && IT == 1) LN_BU(LP, IT, (IT == 1 ? 4 : 1)); \
+                          else if (lnb_u >= 2 && IT <= 2) LN_BU(LP, IT, (IT <= 2 ? 2 : 1)); else LN_BU(LP, IT, 1); } while (0)
   if (lpr == 16) LN_B(16, 1);
   else if (lpr == 32) LN_B(32, 1);
   else if (iters == 1) LN_B(64, 1);
