@@ -615,19 +615,21 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
   }
   // Early MViT blocks (C = 96 / 192 at 10^5 - 10^6 rows): HBM-bound products with a reduction of a few k-steps.  The streaming
   // panel kernel (gemm_stream.hip: weight resident in LDS, every wave on its own rows, no barriers) was built for all of them and
-  // MEASURED against the tiled kernels (tools/stream_bench.py, profiles/r03_stream_bench.txt): it wins only where the output is wide
-  // and the epilogue is a plain bias — qkv of blocks 0-3: 1.06-1.22x — and loses everywhere else (N = C outputs 0.63-0.98x: the
-  // tiled kernels already stream those at 4.5-5.3 TB/s; two-tensor / gelu' epilogues 0.60-0.85x: a lane pair's 16-byte pieces cover
-  // only 32 bytes of a row per store / load instruction, against the tiled kernels' LDS-transposed full 128-byte lines — and 0.34x
-  // when the saved pre-activation used the non-temporal hint, which sends such partial lines to HBM as they are).
-  // So it takes exactly the shapes it wins; DCC_STREAM_GEMM=0 disables it, =2 (or variant 12: tests, tools/stream_bench.py) widens
-  // it to its whole domain.
+  // MEASURED against the tiled kernels (tools/stream_bench.py).  With direct 16-byte stores from the accumulator layout it won only
+  // the plain-bias wide outputs (profiles/r03_stream_bench.txt: a lane pair covers 32 bytes of a row per store instruction); since
+  // its column tiles leave in pairs through a wave-private LDS strip as complete 128-byte lines (and the epilogue flags are
+  // compile-time) it wins every product with K <= 192 and N >= 192 — qkv 1.03-1.29x, project 1.12-1.36x, fc1 with GELU and the
+  // saved pre-activation 1.09-1.11x, gelu' 1.12-1.25x (profiles/r03_stream_bench_staged.txt) — and still loses the N = 96 outputs
+  // (0.83-0.93x: three column tiles = one pair + one direct tile, and the tiled kernels stream those at 4.5-5.3 TB/s).
+  // DCC_STREAM_GEMM=0 disables it, =3 restores round 3's first rule (plain bias, N >= 288), =2 (or variant 12: tests,
+  // tools/stream_bench.py) widens it to its whole domain.
   static const int stream_mode = getenv("DCC_STREAM_GEMM") ? atoi(getenv("DCC_STREAM_GEMM")) : 1;
   const bool stream_all = stream_mode == 2 || variant == 12;
+  const bool stream_pick = stream_mode == 3 ? (K <= 192 && N >= 288 && !(flags & (GEMM_GELU | GEMM_DGELU | GEMM_SAVE_PRE | GEMM_RESID)))
+                                            : (K <= 192 && N >= 192);
   if ((stream_mode || variant == 12) && in_dtype == DCC_BF16 && out_dtype == DCC_BF16 && aligned && (variant == 0 || variant == 12) &&
       !a_km && !b_km && batch == 1 && splitk == 1 && !(flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && M >= 16384 && K <= 576 &&
-      (K <= 192 || N <= 192) &&
-      (stream_all || (K <= 192 && N >= 288 && !(flags & (GEMM_GELU | GEMM_DGELU | GEMM_SAVE_PRE | GEMM_RESID))))) {
+      (K <= 192 || N <= 192) && (stream_all || stream_pick)) {
     const int rc = dcc_gemm_stream_launch(p, st);
     if (rc != DCC_ERR_UNSUPPORTED) return rc;
   }

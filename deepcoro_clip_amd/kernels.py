@@ -153,19 +153,24 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_km: bool = False, b_km: bool = F
     return out
 
 
-STREAM_GEMM = int(_os.environ.get("DCC_STREAM_GEMM", "1"))   # 0: off; 1: the shapes it wins (plain wide outputs); 2: whole domain (tests, A/B)
+STREAM_GEMM = int(_os.environ.get("DCC_STREAM_GEMM", "1"))   # 0: off; 1: the shapes it wins (K <= 192, N >= 192); 2: whole domain (tests, A/B); 3: plain-bias wide outputs only
 
 
 def stream_gemm_shape(M: int, N: int, K: int, dtype: torch.dtype) -> bool:
-    """Domain of the streaming panel GEMM (csrc/gemm_stream.hip, chosen inside dcc_gemm): bf16 row-major x row-major with the
-    weight resident in LDS — the early MViT blocks' products.  Mirrors the C-side test so that a data-gradient product
-    g W (k-major weight) can be handed over with a transposed weight shadow instead (functional._dx_gemm)."""
+    """Shapes dcc_gemm hands to the streaming panel GEMM (csrc/gemm_stream.hip): bf16 row-major x row-major with the weight
+    resident in LDS — the early MViT blocks' products.  Mirrors the C-side test so that a data-gradient product g W (k-major
+    weight) can be handed over with a transposed weight shadow instead (functional._dx_gemm): since the kernel stores complete
+    lines through LDS it wins K <= 192 with N >= 192, i.e. the gelu' products of blocks 0-2 (profiles/r03_stream_bench_staged.txt)."""
     whole = STREAM_GEMM == 2 or (GEMM_VARIANT >> 8) == 12   # variant 12: tests / tools force the kernel's whole domain
-    if not whole or dtype != torch.bfloat16 or M < 16384 or K not in (96, 192, 288, 384, 576) or N % 32:
-        return False   # data-gradient products (N = C outputs) measured SLOWER on the streaming kernel: only in its "whole domain" mode
+    if STREAM_GEMM == 0 and not whole:
+        return False
+    if dtype != torch.bfloat16 or M < 16384 or K not in (96, 192, 288, 384, 576) or N % 32 or (GEMM_VARIANT >> 8) not in (0, 12):
+        return False
     if not (K <= 192 or N <= 192):
         return False
-    nc = ((150 * 1024) // (2 * K + 16 + 4)) & ~31
+    if not whole and (STREAM_GEMM == 3 or not (K <= 192 and N >= 192)):   # mode 3: round 3's first rule never took data gradients
+        return False
+    nc = ((150 * 1024 - 9216) // (2 * K + 16 + 4)) & ~31
     return nc >= 32 and -(-N // nc) <= 4
 
 
