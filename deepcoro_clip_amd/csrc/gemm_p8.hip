@@ -35,7 +35,9 @@ constexpr int PNT = 512;
 constexpr int PIECE_B = 128 * 128;          // 128 rows x 64 k bf16
 constexpr int KT_B = 4 * PIECE_B;           // one K-tile: S0 S1 S2 S3
 constexpr int PBIAS_OFF = 2 * KT_B;         // two 1-KB bias slots (item parity)
-constexpr int P8_LDS = PBIAS_OFF + 2 * 1024;
+constexpr int PSTG_OFF = PBIAS_OFF + 2 * 1024;   // 8 wave-private store-staging strips: 8 rows x (128 + 16) bytes
+constexpr int PSTG_PITCH = 144, PSTG_WAVE = 8 * PSTG_PITCH;
+constexpr int P8_LDS = PSTG_OFF + 8 * PSTG_WAVE;
 
 struct P8Geo { int items, tilesN, nk, dbg, stagger; };   // stagger: 2048-cycle sleeps before the first tile of a workgroup that has one item fewer   // dbg (DCC_P8_DEBUG, experiments): 1 = no stores, 2 = no epilogue
 
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(PNT, 1) void gemm_p8_kernel(GemmParams p, P8Geo geo
       bf16_t* crow = C + lrow * p.ldc + n0 + 8 * h;
       bf16_t* arow = (F & (GEMM_SAVE_PRE | GEMM_DGELU)) ? AUX + lrow * p.ldaux + n0 + 8 * h : nullptr;
       const bf16_t* rrow = (F & GEMM_RESID) ? R + lrow * p.ldr + n0 + 8 * h : nullptr;
+      u32x4 cfin[2][2], cpre[2][2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         uint32_t pk[8];   // round once after alpha * acc + bias
@@ -183,9 +186,7 @@ __global__ __launch_bounds__(PNT, 1) void gemm_p8_kernel(GemmParams p, P8Geo geo
           const int co = 32 * j + 16 * P;                               // element offset from the row pointers (+ 8 h inside them)
           const bool ok = full || (live && n0 + co + 8 * h < p.N);      // N % 8 == 0: a 16-byte piece is inside or outside
           const int lco = ok ? co : -(n0 + 8 * h);                      // dead pieces read column 0 of a valid row
-          if (F & GEMM_SAVE_PRE) {
-            if (ok) *reinterpret_cast<u32x4*>(arow + co) = c;
-          }
+          cpre[j][P] = c;
           if (F & (GEMM_GELU | GEMM_DGELU | GEMM_RESID)) {
             float v[8];
             punpack8(c, v);
@@ -210,9 +211,46 @@ __global__ __launch_bounds__(PNT, 1) void gemm_p8_kernel(GemmParams p, P8Geo geo
 #pragma unroll
             for (int q = 0; q < 4; ++q) c[q] = ppack2(v[2 * q], v[2 * q + 1]);
           }
-          if (geo.dbg & 1) asm volatile("" ::"v"(c));
-          else if (ok) *reinterpret_cast<u32x4*>(crow + co) = c;
+          cfin[j][P] = c;
         }
+      }
+      if (n0 + 64 <= p.N && !(geo.dbg & 4)) {
+        // complete 128-byte lines through the wave's LDS strip (as gemm_stream.hip): pass q = rows 8q .. 8q+7 of this 32-row slab; the
+        // 16 lanes that own them write their 4 x 16 bytes, every lane reads 16 bytes back and stores row 8q + lane / 8, bytes 16 (lane & 7)
+        char* stg = smem + PSTG_OFF + wid * PSTG_WAVE;
+        char* stg_w = stg + (lane & 7) * PSTG_PITCH + 16 * h;
+        const char* stg_r = stg + (lane >> 3) * PSTG_PITCH + 16 * (lane & 7);
+        const int r = lane & 31;
+#pragma unroll
+        for (int pass = 0; pass < ((F & GEMM_SAVE_PRE) ? 2 : 1); ++pass) {
+          const bool pre = pass == 0 && (F & GEMM_SAVE_PRE);
+          bf16_t* base = pre ? AUX : C;
+          const int64_t ld = pre ? p.ldaux : p.ldc;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if ((r >> 3) == q) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int P = 0; P < 2; ++P) *reinterpret_cast<u32x4*>(stg_w + 64 * j + 32 * P) = pre ? cpre[j][P] : cfin[j][P];
+            }
+            const u32x4 o = *reinterpret_cast<const u32x4*>(stg_r);
+            const int srow = m0 + 32 * i + 8 * q + (lane >> 3);
+            if (geo.dbg & 1) asm volatile("" ::"v"(o));
+            else if (srow < p.M) *reinterpret_cast<u32x4*>(base + (int64_t)srow * ld + n0 + 8 * (lane & 7)) = o;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int P = 0; P < 2; ++P) {
+            const int co = 32 * j + 16 * P;
+            const bool ok = full || (live && n0 + co + 8 * h < p.N);
+            if ((F & GEMM_SAVE_PRE) && ok) *reinterpret_cast<u32x4*>(arow + co) = cpre[j][P];
+            if (geo.dbg & 1) asm volatile("" ::"v"(cfin[j][P]));
+            else if (ok) *reinterpret_cast<u32x4*>(crow + co) = cfin[j][P];
+          }
       }
     }
     c_item += G;
