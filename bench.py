@@ -300,7 +300,7 @@ def main():
                 if rec.get("workload") == [args.dtype, args.batch, args.videos, args.frames, args.size, args.pooling]:
                     traffic = rec.get("hbm_bytes_per_launch")
                     break
-            roofline = {"bound": bound, "kernel": "bf16 GEMM family (gemm_ring2_kernel / gemm_ring_kernel / gemm_wide_kernel / gemm_kernel)"
+            roofline = {"bound": bound, "kernel": "bf16 GEMM family (gemm_ring2_kernel / gemm_ring_kernel / gemm_wide_kernel / gemm_stream_kernel / gemm_kernel)"
                         if args.dtype == "bf16" else "fp32 GEMM family (gemm_kernel)",
                         "achieved": round(tflops if bound == "mfma" else gbs, 2), "peak": peak if bound == "mfma" else HBM_PEAK_GBS,
                         "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(max(mfma_frac, hbm_frac), 4),
