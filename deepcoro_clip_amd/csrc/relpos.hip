@@ -360,6 +360,16 @@ __global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(
     pr.g[0] = pr.live ? reinterpret_cast<const u32x4*>(dQf + off + g.D + part * apq)[0] : z4;
     pr.g[1] = (pr.live && apq > 8) ? reinterpret_cast<const u32x4*>(dQf + off + g.D + part * apq)[1] : z4;
   };
+  int64_t pend = -1;   // !LN: tile whose finished dq sits in Rz
+  auto copy_out = [&]() {
+    if (pend < 0) return;
+    const int64_t orow = pend * 64 + r;
+    if (orow < (int64_t)rows) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        reinterpret_cast<u32x4*>(dq + orow * g.D)[part * 3 + c] = reinterpret_cast<const u32x4*>(Rz + r * RZP)[part * 3 + c];
+    }
+  };
   auto do_tile = [&](Pre& pr, unsigned tile) {
     const unsigned long long t1 = RBT();
     __syncthreads();   // the previous tile's fragment reads are done (and, first time, the tables are staged)
@@ -369,11 +379,13 @@ __global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(
     const bool live = pr.live;
     const u32x4 gr[2] = {pr.g[0], pr.g[1]};
     for (int i = tid; i < zunits; i += 256) reinterpret_cast<u32x4*>(dP)[i] = z4;
+    if constexpr (!LN) copy_out();   // the previous tile's dq rows (each thread re-reads the three pieces it is about to overwrite)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       reinterpret_cast<u32x4*>(Qs + r * 192)[part * 3 + c] = pr.q[c];
       reinterpret_cast<u32x4*>(Rz + r * RZP)[part * 3 + c] = pr.z[c];
     }
+    pend = (int64_t)tile;
     prefetch(pr, tile + (NMT == 2 ? 2 : 1) * gridDim.x);
     __syncthreads();   // zeros are in place
     RBP(2, t2);
@@ -456,14 +468,15 @@ __global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(
           const unsigned orow = tile * 64u + 32 * i + (lane & 31);
           if (orow < rows) {
             const char* res = Rz + (32 * i + (lane & 31)) * RZP + (32 * wave + 4 * h) * 2;
-            bf16_t* dst = dq + (int64_t)orow * g.D + 32 * wave + 4 * h;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
               const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + 16 * g4);
               bf16x4 o;
 #pragma unroll
               for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[i][4 * g4 + e] + (float)rv[e]);
-              *reinterpret_cast<bf16x4*>(dst + 8 * g4) = o;
+              // the finished value replaces its residual in LDS; the tile leaves at the start of the next one as whole rows
+              // (48 bytes per thread, 4 threads per 192-byte row) instead of 8-byte pieces of 32 different rows per store
+              *reinterpret_cast<bf16x4*>(const_cast<char*>(res) + 16 * g4) = o;
             }
           }
         }
@@ -556,6 +569,10 @@ __global__ __launch_bounds__(256, NMT == 1 ? 2 : 1) void relpos_bwd_mfma_kernel(
     if constexpr (DIST == 2) {
       if (tile + gridDim.x < ntiles) do_tile(preB, tile + gridDim.x);   // block-uniform
     }
+  }
+  if constexpr (!LN) {
+    __syncthreads();   // the last tile's epilogue writes
+    copy_out();
   }
   const unsigned long long t6 = RBT();
   // ---- this block's table gradient -> workspace [block][g.L][96] (+ [2][96] LayerNorm parameter partials with LN)
