@@ -181,27 +181,58 @@ __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 
 // store a transposed accumulator tile: value for (row = n, col = 32*t + acc_row(reg,h)) lives in
 // acc[reg] of the lane with (lane&31) == n - n0.  4 consecutive regs = 4 consecutive columns.
-template <typename T>
+// PAIR = false keeps four 8-byte stores: measured faster in the DQK = 160 backward kernels (block 1: 1 401 vs 1 452 us), whose five
+// column tiles leave no registers for the packed copies
+template <typename T, bool PAIR = true>
 __device__ __forceinline__ void store_tile_T(T* rowptr, int t, int h, const f32x16& acc, float mul,
                                              const T* resptr) {
+  if constexpr (sizeof(T) == 2 && PAIR) {
+    // bf16: the lane pair (l, l + 32) holds columns 8 g4 + 4 h .. + 3 of the same row; after a half exchange per pair of column
+    // groups the lower lane owns columns 16 P .. + 7 and the upper lane 16 P + 8 .. + 15: two 16-byte stores per tile instead of four
+    // 8-byte ones (both lanes of a pair are always active together: the callers' row guard depends on lane & 31 only)
+    uint32_t pk[8];
 #pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4) {
-    const int col = 32 * t + 8 * g4 + 4 * h;
-    float v[4];
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int col = 32 * t + 8 * g4 + 4 * h;
+      float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = acc[4 * g4 + e] * mul;
-    if (resptr) {
+      for (int e = 0; e < 4; ++e) v[e] = acc[4 * g4 + e] * mul;
+      if (resptr) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += to_f32(resptr[col + e]);
+        for (int e = 0; e < 4; ++e) v[e] += to_f32(resptr[col + e]);
+      }
+      bf16x2 lo, hi;
+      lo[0] = (bf16_t)v[0]; lo[1] = (bf16_t)v[1]; hi[0] = (bf16_t)v[2]; hi[1] = (bf16_t)v[3];
+      pk[2 * g4] = __builtin_bit_cast(uint32_t, lo);
+      pk[2 * g4 + 1] = __builtin_bit_cast(uint32_t, hi);
     }
-    if constexpr (sizeof(T) == 2) {
-      bf16x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-      *reinterpret_cast<bf16x4*>(rowptr + col) = o;
-    } else {
-      f32x4 o = {v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(rowptr + col) = o;
+    for (int P = 0; P < 2; ++P) {
+      const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * P], pk[4 * P + 2], false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * P + 1], pk[4 * P + 3], false, false);
+      const u32x4 c = {s0[0], s1[0], s0[1], s1[1]};
+      *reinterpret_cast<u32x4*>(rowptr + 32 * t + 16 * P + 8 * h) = c;
+    }
+  } else {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int col = 32 * t + 8 * g4 + 4 * h;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[4 * g4 + e] * mul;
+      if (resptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += to_f32(resptr[col + e]);
+      }
+      if constexpr (sizeof(T) == 2) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+        *reinterpret_cast<bf16x4*>(rowptr + col) = o;
+      } else {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(rowptr + col) = o;
+      }
     }
   }
 }
@@ -457,7 +488,7 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
     // residual shortcut O += Qf[:, :DV] (q >= res_start): its gradient dO lands in the first DV columns of dQ
     const T* rrow = (p.Qres && myq >= p.res_start) ? dO + (int64_t)myq * p.son : nullptr;
 #pragma unroll
-    for (int t = 0; t < DQK / 32; ++t) store_tile_T<T>(drow, t, h, dq[t], p.scale, (32 * t < DV) ? rrow : nullptr);
+    for (int t = 0; t < DQK / 32; ++t) store_tile_T<T, (DQK <= 128)>(drow, t, h, dq[t], p.scale, (32 * t < DV) ? rrow : nullptr);
   }
 }
 
@@ -584,9 +615,9 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
       TO* dkrow = reinterpret_cast<TO*>(p.dK) + b * p.sdkb + hd * p.sdkh + (int64_t)mykey * p.sdkn;
       TO* dvrow = reinterpret_cast<TO*>(p.dV) + b * p.sdvb + hd * p.sdvh + (int64_t)mykey * p.sdvn;
 #pragma unroll
-      for (int t = 0; t < DQK / 32; ++t) store_tile_T<TO>(dkrow, t, h, dk[t], p.scale, nullptr);
+      for (int t = 0; t < DQK / 32; ++t) store_tile_T<TO, (DQK <= 128)>(dkrow, t, h, dk[t], p.scale, nullptr);
 #pragma unroll
-      for (int t = 0; t < DV / 32; ++t) store_tile_T<TO>(dvrow, t, h, dvv[t], 1.0f, nullptr);
+      for (int t = 0; t < DV / 32; ++t) store_tile_T<TO, (DQK <= 128)>(dvrow, t, h, dvv[t], 1.0f, nullptr);
     }
   } else if constexpr (sizeof(TO) == 4) {
     // query-split partial sums: transpose each wave's [32 keys][D] tile through LDS so that one atomic
@@ -713,7 +744,8 @@ extern "C" int dcc_attn_bwd(const void* Q, const void* K, const void* V, const v
   int rc = check_common(p, dtype);
   if (rc) return rc;
   for (int i = 12; i < 21; ++i)
-    if (strides[i] % 4) return DCC_ERR_UNSUPPORTED;
+    if (strides[i] % (dtype == DCC_BF16 ? 8 : 4)) return DCC_ERR_UNSUPPORTED;   // 16-byte output pieces
+  if (((uintptr_t)dQ & 15) || ((uintptr_t)dK & 15) || ((uintptr_t)dV & 15)) return DCC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype != DCC_BF16 && dtype != DCC_F32) return DCC_ERR_UNSUPPORTED;
   const int out_f32 = (qsplit > 1) || dtype == DCC_F32;
