@@ -255,6 +255,7 @@ def main():
         host_free.append(time.perf_counter() - th)
     barrier()
     host_free_ms = 1e3 * sorted(host_free)[1]
+    peak_hbm_gb = round(torch.cuda.max_memory_allocated() / 2**30, 1)   # of the product path: before the instrumented pass below
     if rank == 0:
         print(f"[bench] host enqueue {1e3 * t_host / args.steps:.2f} ms/step in the timed region (queue back-pressure included), "
               f"{host_free_ms:.2f} ms/step into an empty queue; wall {1e3 * dt / args.steps:.2f} ms/step", file=sys.stderr, flush=True)
@@ -318,7 +319,12 @@ def main():
         # stream; algorithmic FLOPs = forward_macs (128.45 GFLOP per 16x224^2 clip) + proj + pooling heads
         from deepcoro_clip_amd.mvit import forward_macs
         ve = runner.video_encoder.module if hasattr(runner.video_encoder, "module") else runner.video_encoder
-        clips = args.batch * max(1, args.videos)
+        fwd_videos = batch["videos"]
+        if args.micro_batch and fwd_videos.shape[0] > args.micro_batch:
+            # embedding-cache workloads never hold the whole batch's activations: time ONE micro-batch's forward (r03: this leg ran
+            # all 512 clips of configs[3] at once and put 272.7 GB into the line's peak-memory field)
+            fwd_videos = fwd_videos[:args.micro_batch]
+        clips = fwd_videos.shape[0] * max(1, args.videos)
         tokens = ve.model.plan[-1]["q_thw"][0] * ve.model.plan[-1]["q_thw"][1] * ve.model.plan[-1]["q_thw"][2] + 1
         flop_clip = 2.0 * forward_macs(ve.model.plan)["total"] + 2.0 * tokens * 768 * 512
         if args.pooling == "attention":
@@ -326,13 +332,13 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = max(3, min(args.steps, 10))
-        ve(batch["videos"])  # warm
+        ve(fwd_videos)  # warm
         fwd_ms, host_s = float("inf"), 0.0
         for _ in range(2):   # two timed batches, the faster one counts (a cold host can starve the first)
             th0 = time.perf_counter()
             e0.record()
             for _ in range(reps):
-                out_v = ve(batch["videos"])
+                out_v = ve(fwd_videos)
                 del out_v
             e1.record()
             th1 = time.perf_counter()
@@ -372,7 +378,8 @@ def main():
                        "global_batch": pairs_per_step, "clips_per_step": clips_per_step, "seq_len": args.seq,
                        "parallelism": f"dp{world}", "loss_first": loss0, "loss_last": m["loss"],
                        "step_graph": step_graph, "host_ms_per_step_unblocked": round(host_free_ms, 2),
-                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)},
+                       "peak_hbm_gb": peak_hbm_gb,
+                       "peak_hbm_gb_instrumented_pass": round(torch.cuda.max_memory_allocated() / 2**30, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

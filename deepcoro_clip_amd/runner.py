@@ -391,10 +391,13 @@ class VideoContrastiveLearningRunner:
                     text_metadata: Optional[List[Dict[str, Any]]] = None,
                     debug_sample_info: Optional[List[Dict[str, Any]]] = None) -> tuple[dict, dict]:
         accum = int(_cfg(self.config, "gradient_accumulation_steps", 1))
-        if self._graph_eligible(accum, positive_mask, text_metadata):
-            return self._graph_train_step(videos, input_ids, attention_mask)
         micro = int(_cfg(self.config, "embedding_cache_micro_batch", 0) or 0)
-        if micro > 0 and videos.shape[0] > micro and input_ids is not None:
+        cached = micro > 0 and videos.shape[0] > micro and input_ids is not None
+        # the two-pass embedding-cache step exists to bound activation memory: it is never replaced by a one-shot captured step
+        # (r03: `bench.py --config siglip4096` with the step graph on ran all 512 clips at once, 272 GB instead of 24.6)
+        if not cached and self._graph_eligible(accum, positive_mask, text_metadata):
+            return self._graph_train_step(videos, input_ids, attention_mask)
+        if cached:
             total_loss, video_emb, text_emb, diag = self._forward_backward_cached(
                 videos, input_ids, attention_mask, positive_mask, positive_weights, text_metadata, accum, micro)
         else:

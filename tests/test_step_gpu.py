@@ -346,6 +346,14 @@ def test_embedding_cache_two_pass_equals_one_shot(loss_name):
     rb.config.embedding_cache_micro_batch = 8
     m, emb = rb._train_step(videos=videos.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda())
     assert math.isfinite(m["loss"]) and emb["video_embeddings"].shape == (B, 512) and "alignment_score" in m
+    # the step graph never replaces the two-pass step (it would run the whole batch at once: the memory bound is the point)
+    rb._use_step_graph = True
+    calls = []
+    orig = rb._forward_backward_cached
+    rb._forward_backward_cached = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    for _ in range(5):   # more calls than the graph path's eager warm-up
+        rb._train_step(videos=videos.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda())
+    assert len(calls) == 5 and not any(st.get("graph") is not None for st in rb._graphs.values())
 
 
 def test_embedding_cache_redraws_the_same_masks():
