@@ -15,7 +15,7 @@ import torch
 # DCC_LIB: alternative build of the same library (kernel A/B runs from tools/, see build.build_variant)
 LIB_PATH = Path(os.environ.get("DCC_LIB") or (Path(__file__).resolve().parent / "libdcc_hip.so"))
 
-DCC_F32, DCC_BF16 = 0, 1
+DCC_F32, DCC_BF16, DCC_F16 = 0, 1, 2
 _ERR = {-1: "DCC_ERR_ARG", -2: "DCC_ERR_LAUNCH", -3: "DCC_ERR_UNSUPPORTED"}
 
 
@@ -82,6 +82,8 @@ def dt(t_or_dtype) -> int:
         return DCC_F32
     if d == torch.bfloat16:
         return DCC_BF16
+    if d == torch.float16:  # dcc_cast only: fp16 wire format of the SigLIP embedding gather
+        return DCC_F16
     raise DccError(f"unsupported dtype {d}")
 
 

@@ -18,6 +18,7 @@
 // dtype codes of the C ABI
 #define DCC_F32 0
 #define DCC_BF16 1
+#define DCC_F16 2   // dcc_cast only: the fp16 wire format of the SigLIP embedding gather
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

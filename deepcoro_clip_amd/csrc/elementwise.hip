@@ -42,6 +42,15 @@ __global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_
     d[i] = from_f32<TD>(to_f32(s[i]));
 }
 
+// fp32 <-> IEEE fp16: the wire format of SiglipLossDDP's embedding all-gather (utils/loss/losses.py:243-248 rounds the
+// embeddings to half before the gather, and autograd rounds the returning gradient to half on the way back)
+__global__ void cast_f32_f16_kernel(const float* __restrict__ s, _Float16* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (_Float16)s[i];
+}
+__global__ void cast_f16_f32_kernel(const _Float16* __restrict__ s, float* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (float)s[i];
+}
+
 // strided 2-D cast/copy: d[r*ldd + c] = s[r*lds + c]
 template <typename TS, typename TD>
 __global__ void cast2d_kernel(const TS* __restrict__ s, int64_t lds_, TD* __restrict__ d, int64_t ldd, int64_t rows,
@@ -556,6 +565,8 @@ extern "C" int dcc_cast(const void* src, void* dst, int64_t n, int src_dtype, in
   else if (src_dtype == DCC_BF16 && dst_dtype == DCC_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, dim3(256), 0, ST, (const bf16_t*)src, (float*)dst, n);
   else if (src_dtype == DCC_F32 && dst_dtype == DCC_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, dim3(256), 0, ST, (const float*)src, (float*)dst, n);
   else if (src_dtype == DCC_BF16 && dst_dtype == DCC_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, dim3(256), 0, ST, (const bf16_t*)src, (bf16_t*)dst, n);
+  else if (src_dtype == DCC_F32 && dst_dtype == DCC_F16) hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(gs_blocks(n, 1)), dim3(256), 0, ST, (const float*)src, (_Float16*)dst, n);
+  else if (src_dtype == DCC_F16 && dst_dtype == DCC_F32) hipLaunchKernelGGL(cast_f16_f32_kernel, dim3(gs_blocks(n, 1)), dim3(256), 0, ST, (const _Float16*)src, (float*)dst, n);
   else return DCC_ERR_UNSUPPORTED;
   return dcc_check_launch();
 }

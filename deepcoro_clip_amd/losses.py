@@ -192,14 +192,33 @@ class SiglipLoss(nn.Module):
         return pair_loss(video_features, text_features, _lt(log_temp, video_features), mode=MODE_GATED, kind=KIND_CE)
 
 
+class _WireCastFn(torch.autograd.Function):
+    """x -> dtype on the way in, the gradient -> x's dtype on the way back (both roundings happen, as under autograd's
+    `.half()` / `.float()` pair)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return K.cast(x.detach().contiguous(), dtype)
+
+    @staticmethod
+    def backward(ctx, d):
+        return K.cast(d.contiguous(), ctx.src), None
+
+
 @LossRegistry.register("siglip_ddp")
 class SiglipLossDDP(nn.Module):
-    """utils/loss/losses.py:213-276 (the reference gathers in fp16 to cut traffic; we gather bf16-rounded values
-    only when the embeddings already are bf16, otherwise fp32 — 1 MB per rank at B=512 is latency-bound anyway)."""
+    """utils/loss/losses.py:213-276.  The reference rounds both embedding matrices to fp16 BEFORE the gather (:243-244,
+    half the wire bytes) and normalises the gathered halves in fp32 (:247-248); autograd then rounds the returning gradient
+    to fp16 as well.  Reproduced bit for bit at every world size (world 1 included: `.half()` is applied before
+    `gather_all` decides whether to gather): fp32 -> fp16 -> all_gather(fp16) -> fp32."""
 
     def forward(self, video_features, text_features, log_temp=None):
-        v, t = gather_all(video_features), gather_all(text_features)
-        return pair_loss(v, t, _lt(log_temp, video_features), mode=MODE_GATED, kind=KIND_CE)
+        def wire(x):
+            x32 = x if x.dtype == torch.float32 else _WireCastFn.apply(x, torch.float32)
+            return _WireCastFn.apply(gather_all(_WireCastFn.apply(x32, torch.float16)), torch.float32)
+
+        return pair_loss(wire(video_features), wire(text_features), _lt(log_temp, video_features), mode=MODE_GATED, kind=KIND_CE)
 
 
 @LossRegistry.register("InfoNCE")

@@ -30,6 +30,7 @@ extern "C" {
 #define DCC_ERR_UNSUPPORTED (-3)
 #define DCC_F32 0
 #define DCC_BF16 1
+#define DCC_F16 2 /* dcc_cast only (f32 <-> f16): wire format of SiglipLossDDP's gather, utils/loss/losses.py:243-248 */
 
 /* GEMM epilogue flags */
 #define DCC_GEMM_BIAS 1

@@ -116,6 +116,29 @@ def losses():
     np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
 
 
+def losses_ddp():
+    """ContrastiveLossDDP / SiglipLossDDP (utils/loss/losses.py:104-158, 213-276) at world size 1 — `gather_all` returns its
+    input when no process group exists, but SiglipLossDDP's fp16 round trip (`.half()` before the gather, `.float()` after)
+    still happens, in the value and in the gradient."""
+    from utils.loss import losses as Ls
+
+    out = {}
+    for B, scale in ((8, 1.0), (24, 1.0), (16, 37.0)):  # the third case: large-norm embeddings (fp16 rounding is relative)
+        g = torch.Generator().manual_seed(11 + B)
+        v = (scale * torch.randn(B, 512, generator=g)).requires_grad_(True)
+        t = (scale * torch.randn(B, 512, generator=g)).requires_grad_(True)
+        lt = torch.log(torch.tensor(0.07)).requires_grad_(True)
+        out[f"v{B}"], out[f"t{B}"] = np_(v), np_(t)
+        for name, mod in (("contrastive_ddp", Ls.ContrastiveLossDDP()), ("siglip_ddp", Ls.SiglipLossDDP())):
+            for x in (v, t, lt):
+                x.grad = None
+            loss = mod(v, t, lt)
+            loss.backward()
+            out[f"{name}{B}_loss"] = np_(loss)
+            out[f"{name}{B}_dv"], out[f"{name}{B}_dt"], out[f"{name}{B}_dlt"] = np_(v.grad), np_(t.grad), np_(lt.grad)
+    np.savez_compressed(os.path.join(OUT, "losses_ddp.npz"), **out)
+
+
 def rope():
     R = load_by_path("ref_rope_3d", "models/rope_3d.py")
     out = {}
@@ -371,7 +394,7 @@ def loss_zoo():
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:]
-    for fn in (losses, rope, pools, bert, retrieval, loss_zoo, pools2, mil, mil_view, pools_masked):
+    for fn in (losses, rope, pools, bert, retrieval, loss_zoo, pools2, mil, mil_view, pools_masked, losses_ddp):
         if only and fn.__name__ not in only:
             continue
         fn()

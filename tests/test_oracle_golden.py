@@ -340,3 +340,25 @@ def test_oracle_depthwise_pool_equals_aten_conv3d(stride):
     assert tuple(ref.shape[2:]) == out_thw
     ref = torch.cat((tok[:, :, :1], ref.reshape(B, Hh, C, -1).transpose(2, 3)), dim=2)
     assert (out - torch.nn.functional.layer_norm(ref, (C,))).abs().max() < 1e-10
+
+
+@pytest.mark.parametrize("B", [8, 24, 16])
+@pytest.mark.parametrize("name", ["contrastive_ddp", "siglip_ddp"])
+def test_ddp_loss_classes_match_reference(B, name):
+    """ContrastiveLossDDP / SiglipLossDDP (utils/loss/losses.py:104-158, 213-276) imported at world size 1 by make_golden.py.
+    SiglipLossDDP's fp16 wire format shows in the gradients: they are fp16-representable numbers."""
+    from oracle.losses import contrastive_loss_ddp, siglip_loss_ddp
+
+    g = _load("losses_ddp.npz")
+    v = _t(g[f"v{B}"]).requires_grad_(True)
+    t = _t(g[f"t{B}"]).requires_grad_(True)
+    lt = torch.log(torch.tensor(0.07)).requires_grad_(True)
+    loss = (contrastive_loss_ddp if name == "contrastive_ddp" else siglip_loss_ddp)(v, t, lt)
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{name}{B}_loss"])) < 1e-6
+    for got, key in ((v.grad, "dv"), (t.grad, "dt")):
+        ref = g[f"{name}{B}_{key}"]
+        assert np.allclose(got.numpy(), ref, atol=1e-7, rtol=1e-6)
+        if name == "siglip_ddp":
+            assert np.array_equal(ref, ref.astype(np.float16).astype(np.float32))  # the reference's gradient came back as halves
+    assert abs(lt.grad.item() - float(g[f"{name}{B}_dlt"])) < 1e-5
