@@ -33,9 +33,15 @@ from . import _grad_slots
 
 
 class HipDDP(torch.nn.Module):
-    def __init__(self, module: torch.nn.Module, device_ids=None, bucket_mb: float = 64.0, **_ignored):
+    def __init__(self, module: torch.nn.Module, device_ids=None, bucket_mb: float = 64.0, grad_wire_dtype=None, **_ignored):
         super().__init__()
         self.module = module
+        # optional reduced-precision transport of the gradient buckets (north_star: "reduce-scatter of grads" in reduced
+        # precision over xGMI): the fp32 bucket is rounded to bf16, all-reduced in bf16 (half the wire bytes: 306 instead of
+        # 612 MB per step at the headline shapes) and written back to the fp32 arena.  Default None = fp32 on the wire.
+        if grad_wire_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("grad_wire_dtype must be None, torch.float32 or torch.bfloat16")
+        self._wire = torch.bfloat16 if grad_wire_dtype == torch.bfloat16 else None
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self._params = [p for p in module.parameters()]
         self._bucket_bytes = int(bucket_mb * (1 << 20))
@@ -51,6 +57,8 @@ class HipDDP(torch.nn.Module):
         self._arrivals: list[int] = []
         self._expected: list[list] = []   # per bucket: the parameters whose gradient arrived in the learning backward
         self._deferred: set[int] = set()
+        self._arrived: set[int] = set()   # bucket mode: parameters with an arrival hook that fired in this backward
+        self._relearn = False             # bucket mode: a gradient outside the recorded order arrived -> learn the order again
         self.hook_calls = 0         # Python hook invocations (tests / diagnostics)
         self._sync = True  # reduce from this backward's hooks (False: accumulate-only micro-step of a window)
         # parameters whose gradient nobody zeroes (outside every optimizer group): their arena slot survives
@@ -122,8 +130,13 @@ class HipDDP(torch.nn.Module):
         self._hooks_installed = True
 
     def _install_bucket_hooks(self):
-        """One hook per bucket, on the parameter whose gradient arrived last in the recorded backward."""
-        pos = {pid: i for i, pid in enumerate(self._arrivals)}
+        """One hook per bucket, on the parameter whose gradient arrived last in the recorded backward — plus a cheap arrival
+        hook on every trainable parameter whose `.grad` cannot tell whether THIS backward's gradient has arrived:
+          * parameters outside the recorded order (no gradient in the learning backward).  Their gradient may later be written
+            straight into the arena slot (_grad_slots.take: data_ptr == view), which `finish()` cannot tell from "nothing
+            arrived" — without a hook it could land while the bucket's all-reduce is in flight.  An arrival defers the bucket
+            to `finish()` and sends the wrapper back to learning the order; an arrival behind the bucket's launch raises;
+          * `persistent_grad_ids` (their `.grad` is never None): the bucket is ready only once their hook has fired."""
         by_id = {id(p): p for p in self._order}
         self._expected = [[] for _ in self._buckets]
         last: dict[int, int] = {}
@@ -133,8 +146,14 @@ class HipDDP(torch.nn.Module):
             last[b] = pid
         for h in self._hook_handles:
             h.remove()
-        self._hook_handles = [by_id[pid].register_post_accumulate_grad_hook(self._make_bucket_hook(b)) for b, pid in last.items()]
+        recorded = set(self._arrivals)
+        self._hook_handles = []
+        for q in self._order:  # arrival hooks first: on a shared parameter they run before the bucket hook
+            if q.requires_grad and (id(q) not in recorded or id(q) in self.persistent_grad_ids):
+                self._hook_handles.append(q.register_post_accumulate_grad_hook(self._make_arrival_hook(q, id(q) in recorded)))
+        self._hook_handles += [by_id[pid].register_post_accumulate_grad_hook(self._make_bucket_hook(b)) for b, pid in last.items()]
         self._req_sig = tuple(p.requires_grad for p in self._order)
+        self._persist_sig = frozenset(self.persistent_grad_ids)
         self._mode = "bucket"
 
     def begin_backward(self, sync: bool = True):
@@ -151,27 +170,49 @@ class HipDDP(torch.nn.Module):
                 self._mode = "param"
                 if self._hooks_installed:
                     self._install_param_hooks()
-        if self._hooks_installed and self._req_sig != tuple(p.requires_grad for p in self._order):
-            # the trainable set changed (update_freeze_ratio): hooks follow it, the arrival order is learned again
+        if self._hooks_installed and (self._req_sig != tuple(p.requires_grad for p in self._order) or (
+                self._mode == "bucket" and self._persist_sig != frozenset(self.persistent_grad_ids))):
+            # the trainable set changed (update_freeze_ratio), or the set of never-zeroed gradients did: hooks follow it, the
+            # arrival order is learned again
             if self._mode == "bucket":
                 self._mode = "learn"
             self._install_param_hooks()
         self._fresh = False
         self._arrivals = []
         self._deferred = set()
+        self._arrived = set()
+        self._relearn = False
         self._sync = bool(sync)
         self._pending = [0] * len(self._buckets)
         for p in self._order:
             if p.requires_grad:
                 self._pending[self._bucket_of[id(p)]] += 1
 
+    def _make_arrival_hook(self, p, expected: bool):
+        def hook(_param):
+            self.hook_calls += 1
+            self._arrived.add(id(p))
+            if expected:
+                return
+            # a gradient the recorded backward did not have (a branch unused then, a parameter unfrozen behind our back)
+            self._relearn = True
+            b = self._bucket_of[id(p)]
+            if self.world > 1 and self._sync:
+                if self._pending[b] == 0:
+                    raise RuntimeError("HipDDP: a gradient outside the recorded backward order arrived after its bucket had been "
+                                       "reduced; call begin_backward(sync=False) once (per-parameter hooks) or construct the "
+                                       "wrapper again")
+                self._deferred.add(b)
+
+        return hook
+
     def _make_bucket_hook(self, b: int):
         def hook(_param):
             self.hook_calls += 1
-            ready = True
+            ready = b not in self._deferred
             for q in self._expected[b]:
                 g = q.grad
-                if g is None:
+                if g is None or (id(q) in self.persistent_grad_ids and id(q) not in self._arrived):
                     ready = False      # the arrival order changed: leave the bucket to finish()
                     continue
                 v = self._views[id(q)]
@@ -212,10 +253,14 @@ class HipDDP(torch.nn.Module):
     def _launch(self, b: int):
         lo, hi = self._buckets[b]
         buf = self._arena[lo:hi]
-        if dist.get_backend() == "nccl":
-            self._handles.append((dist.all_reduce(buf, op=dist.ReduceOp.AVG, async_op=True), None))
+        avg = dist.get_backend() == "nccl"   # gloo has no AVG: SUM, then divide in finish()
+        if self._wire is not None:
+            wire = buf.to(self._wire)
+            h = dist.all_reduce(wire, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+            self._handles.append((h, buf, wire, 1.0 if avg else 1.0 / self.world))
         else:
-            self._handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), buf))
+            h = dist.all_reduce(buf, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+            self._handles.append((h, buf, None, 1.0 if avg else 1.0 / self.world))
 
     def finish(self):
         """Join the bucket all-reduces (also launches buckets whose hooks never fired, e.g. unused parameters)."""
@@ -239,6 +284,9 @@ class HipDDP(torch.nn.Module):
                 v.copy_(p.grad)
                 p.grad = v
         learned = self._mode == "learn" and self._sync and bool(self._arrivals)
+        if self._mode == "bucket" and self._relearn:  # the backward is not the recorded one any more: per-parameter hooks again
+            self._mode = "learn"
+            self._install_param_hooks()
         if self.world <= 1:
             if learned:
                 self._install_bucket_hooks()
@@ -250,10 +298,12 @@ class HipDDP(torch.nn.Module):
             if n > 0:
                 self._pending[b] = 0
                 self._launch(b)
-        for h, buf in self._handles:
+        for h, buf, wire, scale in self._handles:
             h.wait()
-            if buf is not None:
-                buf.div_(self.world)
+            if wire is not None:
+                buf.copy_(wire)
+            if scale != 1.0:
+                buf.mul_(scale)
         self._handles = []
         if learned:
             self._install_bucket_hooks()

@@ -892,6 +892,31 @@ def token_mean(x):
     return TokenMeanFn.apply(x)
 
 
+class ClassTokenFn(torch.autograd.Function):
+    """x [B, L, C] -> x[:, 0] as [B, 1, C] (torchvision MViT.forward's `x = x[:, 0]` behind the final norm: the pooled-CLS
+    fallback of backbone="mvit_rope", models/video_encoder.py:552-561); backward scatters into a zero tensor."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, L, C = x.shape
+        ctx.shape = (B, L, C)
+        x = _c(x)
+        out = torch.empty((B, C), device=x.device, dtype=x.dtype)
+        K.cast2d(x.view(B, L * C)[:, :C], out)
+        return out.view(B, 1, C)
+
+    @staticmethod
+    def backward(ctx, d):
+        B, L, C = ctx.shape
+        dx = torch.zeros((B, L * C), device=d.device, dtype=d.dtype)
+        K.cast2d(_c(d).view(B, C), dx[:, :C])
+        return dx.view(B, L, C)
+
+
+def class_token(x):
+    return ClassTokenFn.apply(x)
+
+
 class QPoolFn(torch.autograd.Function):
     """softmax(<q, x_n>) weighted sum over n (EnhancedVideoAggregator tail), fp32."""
 

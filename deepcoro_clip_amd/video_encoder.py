@@ -94,10 +94,10 @@ class VideoEncoder(nn.Module):
             raise NotImplementedError(f"backbone '{backbone}' is outside the MI355X hot path (needs torchvision / torch.hub)")
         else:
             raise ValueError(f"Unsupported backbone: {backbone}")
-        if backbone == "mvit_rope":
-            raise NotImplementedError("backbone 'mvit_rope' takes the reference's pooled-CLS fallback path (L=1, "
-                                      "models/video_encoder.py:544,552-561) which is outside the hot path; use "
-                                      "backbone='mvit', use_rope=True")
+        # backbone="mvit_rope" (models/video_encoder.py:84-90): the reference builds the same trunk, sets use_rope, but patches the
+        # attention blocks only for backbone == "mvit" (:256-257) and routes the forward through torchvision's MViT.forward
+        # (:544, :552-561): norm -> x[:, 0] -> Identity head, i.e. ONE token per clip (L = 1) and no RoPE in the blocks.
+        self._pooled_cls_fallback = backbone == "mvit_rope"
 
         self.proj = nn.Sequential(nn.Dropout(self.dropout), nn.Linear(in_features, output_dim), nn.GELU(), nn.Dropout(self.dropout))
         if output_dim % num_heads != 0:
@@ -186,7 +186,8 @@ class VideoEncoder(nn.Module):
                 raise ValueError("uint8 frames need VideoEncoder.set_input_normalization(mean, std) (pixel units)")
             norm = tuple(t.to(x.device) for t in self.input_norm)
         with Fn.fp8_gemms(self.gemm_dtype == "fp8"):
-            return self.model.forward_features(x, self.compute_dtype, norm)
+            tok = self.model.forward_features(x, self.compute_dtype, norm)
+        return Fn.class_token(tok) if self._pooled_cls_fallback else tok
 
     def _compute_feature_dict(self, x: torch.Tensor, compute_aggregated: bool) -> Dict[str, torch.Tensor]:
         if x.ndim == 5:

@@ -168,10 +168,13 @@ class AggregatorOracle(nn.Module):
 class VideoEncoderOracle(nn.Module):
     def __init__(self, num_frames=16, spatial=(224, 224), output_dim=512, num_heads=4, aggregator_depth=2,
                  token_pooling_mode="mean", attention_pool_heads=8, use_rope=False, rope_base=10000.0,
-                 rope_temporal_scale=1.0, aggregate_videos_tokens=True, per_video_pool=False):
+                 rope_temporal_scale=1.0, aggregate_videos_tokens=True, per_video_pool=False, backbone="mvit"):
         super().__init__()
         self.model = MViTv2S(num_frames, spatial)
-        if use_rope:
+        # backbone="mvit_rope" (models/video_encoder.py:84-90, :256-257, :544-561): RoPE is never patched in and the forward is
+        # torchvision's MViT.forward = norm -> x[:, 0] -> Identity head: one token per clip
+        self.pooled_cls_fallback = backbone == "mvit_rope"
+        if use_rope and backbone == "mvit":
             enable_rope(self.model, rope_base, rope_temporal_scale)
         self.proj = nn.Sequential(nn.Dropout(0.0), nn.Linear(768, output_dim), nn.GELU(), nn.Dropout(0.0))
         self.aggregator = AggregatorOracle(output_dim, num_heads, aggregator_depth)
@@ -186,7 +189,10 @@ class VideoEncoderOracle(nn.Module):
             x = x.unsqueeze(1)
         x = x.permute(0, 1, 5, 2, 3, 4)
         B, N, C, T, H, W = x.shape
-        tok = self.proj(self.model.forward_features(x.reshape(B * N, C, T, H, W).to(self.model.conv_proj.weight.dtype)))
+        feats = self.model.forward_features(x.reshape(B * N, C, T, H, W).to(self.model.conv_proj.weight.dtype))
+        if self.pooled_cls_fallback:
+            feats = feats[:, 0].unsqueeze(1)
+        tok = self.proj(feats)
         L, D = tok.shape[1], tok.shape[2]
         tok = tok.view(B, N, L, D)
         if self.attention_pool is not None:

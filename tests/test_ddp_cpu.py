@@ -219,6 +219,156 @@ def test_hipddp_gradient_accumulation_world2():
     assert [r[1] for r in res] == ["ok", "ok"], res
 
 
+def _bf16_wire_worker(rank, world, port, q):
+    """Optional bf16 bucket transport (half the xGMI bytes): the reduced gradients equal the mean of the per-rank gradients
+    after ONE bf16 rounding of each rank's contribution (relative error <= 2^-8 per element), identical on every rank, and
+    the fp32 default is untouched."""
+    try:
+        _init(rank, world, port)
+        from deepcoro_clip_amd.ddp import HipDDP
+
+        m, ref = _model(seed=0), _model(seed=0)
+        w = HipDDP(m, bucket_mb=0.004, grad_wire_dtype=torch.bfloat16)
+        for it in range(3):
+            w.attach_grads()
+            x, y = _data(rank)
+            ((w(x) - y) ** 2).mean().backward()
+            w.finish()
+            per_rank = []
+            for r in range(world):
+                ref.zero_grad()
+                xr, yr = _data(r)
+                ((ref(xr) - yr) ** 2).mean().backward()
+                per_rank.append([p.grad.clone() for p in ref.parameters()])
+            for i, p in enumerate(m.parameters()):
+                exact = sum(g[i] for g in per_rank) / world
+                wire = sum(g[i].bfloat16().float() for g in per_rank).bfloat16().float() / world   # what the wire computes
+                bound = sum(g[i].abs() for g in per_rank) / world * 2.0 ** -7 + 1e-12
+                assert ((p.grad - exact).abs() <= bound).all(), (it, i, (p.grad - exact).abs().max())
+                assert torch.allclose(p.grad, wire, rtol=2.0 ** -7, atol=1e-9)
+                assert p.grad.dtype == torch.float32
+        flat = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        other = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        assert torch.equal(other[0], other[1])
+        q.put((rank, "ok", 0))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}", 0))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_hipddp_bf16_bucket_transport_world2():
+    res = _run(_bf16_wire_worker)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+
+
+class _SlotLinear(torch.autograd.Function):
+    """y = x W^T whose weight gradient is written straight into the parameter's arena slot (what the HIP weight-gradient GEMMs
+    do through _grad_slots.take): autograd adopts the slot alias, so `grad.data_ptr() == view.data_ptr()` without any copy."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        ctx.w = w
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from deepcoro_clip_amd import _grad_slots
+
+        x, w = ctx.saved_tensors
+        dw = dy.t() @ x
+        slot = _grad_slots.take(ctx.w)
+        if slot is not None:
+            slot.copy_(dw)
+            dw = slot
+        return dy @ w, dw
+
+
+class _Branchy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = torch.nn.Linear(16, 32)
+        self.extra = torch.nn.Parameter(torch.randn(32, 32) * 0.1)   # unused unless use_extra
+        self.b = torch.nn.Linear(32, 8)
+
+    def forward(self, x, use_extra):
+        h = torch.nn.functional.gelu(self.a(x))
+        if use_extra:
+            h = h + _SlotLinear.apply(h, self.extra)
+        return self.b(h)
+
+
+def _late_param_worker(rank, world, port, q):
+    """a parameter without a gradient in the learning backward that gets one later — written straight
+    into its arena slot — must not slip past the one-hook-per-bucket mode: its bucket is deferred to finish(), the values are
+    right on every rank, and the wrapper learns the order again.  Same for a parameter that becomes `persistent`."""
+    try:
+        _init(rank, world, port)
+        from deepcoro_clip_amd.ddp import HipDDP
+
+        m, ref = _Branchy(), _Branchy()
+        w = HipDDP(m, bucket_mb=0.002)   # several buckets; `extra` shares one with neighbours
+        assert len(w._buckets) > 1
+        modes = []
+        for it, use in enumerate([False, False, True, True, True]):
+            w.attach_grads()
+            modes.append(w._mode)
+            x, y = _data(rank)
+            ((w(x, use) - y) ** 2).mean().backward()
+            if it == 2:
+                b = w._bucket_of[id(m.extra)]
+                assert b in w._deferred and w._relearn, "the late gradient must defer its bucket"
+                assert m.extra.grad.data_ptr() == w._views[id(m.extra)].data_ptr()  # it did land in the slot directly
+            w.finish()
+            exp = [torch.zeros_like(p) for p in ref.parameters()]
+            for r in range(world):
+                ref.zero_grad()
+                xr, yr = _data(r)
+                ((ref(xr, use) - yr) ** 2).mean().backward()
+                for e, p in zip(exp, ref.parameters()):
+                    if p.grad is not None:
+                        e += p.grad / world
+            for (n, p), e in zip(m.named_parameters(), exp):
+                assert torch.allclose(p.grad, e, atol=1e-6), (it, n, (p.grad - e).abs().max())
+        assert modes == ["learn", "bucket", "bucket", "learn", "bucket"], modes
+        # a parameter nobody zeroes, declared while in bucket mode: its .grad is never None, so only its arrival hook can say
+        # that this backward's contribution is there; the reduced value = history + mean of the new gradients
+        keep = m.b.weight
+        w.persistent_grad_ids = {id(keep)}
+        hist = keep.grad.clone()
+        for it in range(3):
+            w.attach_grads()
+            x, y = _data(rank)
+            ((w(x, True) - y) ** 2).mean().backward()
+            w.finish()
+            new = torch.zeros_like(hist)
+            for r in range(world):
+                ref.zero_grad()
+                xr, yr = _data(r)
+                ((ref(xr, True) - yr) ** 2).mean().backward()
+                new += ref.b.weight.grad / world
+            hist = hist + new
+            assert torch.allclose(keep.grad, hist, atol=1e-5), (it, (keep.grad - hist).abs().max())
+        assert w._mode == "bucket"
+        q.put((rank, "ok", 0))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}", 0))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_hipddp_late_and_persistent_gradients_in_bucket_mode_world2():
+    res = _run(_late_param_worker)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+
+
 def _val_epoch_worker(rank, world, port, q):
     """_run_epoch('val') on two ranks: every rank issues the same collectives with the same key sets (retrieval metrics are
     computed on the reference rank only, the other rank reports placeholders under identical keys) and all ranks end up

@@ -290,3 +290,30 @@ def test_masked_pools_and_aggregator_match_reference_golden_and_oracle_gradients
     allm = torch.ones(2, 4, dtype=torch.bool); allm[0, 0] = False
     y = agg(torch.randn(2, 4, 512).cuda(), mask=allm.cuda())
     assert torch.all(y[1] == 0) and torch.isfinite(y).all() and y[0].abs().max() > 0
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 5e-2, 2e-1)])
+def test_video_encoder_mvit_rope_backbone_takes_the_pooled_cls_fallback(dtype, tol, gtol):
+    """backbone="mvit_rope" (models/video_encoder.py:84-90): same trunk, use_rope forced on — but the blocks are only patched
+    for backbone == "mvit" (:256-257) and the forward goes through torchvision's MViT.forward (:544, :552-561): the class token
+    behind the final norm as the clip's ONE token (L = 1).  Output + every gradient against the oracle."""
+    from deepcoro_clip_amd.video_encoder import VideoEncoder
+    from oracle.model import VideoEncoderOracle, init_by_name
+
+    T, S, B, N = 4, 64, 2, 2
+    orc = init_by_name(VideoEncoderOracle(T, (S, S), backbone="mvit_rope", use_rope=True)).double()
+    prod = VideoEncoder(backbone="mvit_rope", num_frames=T, spatial_size=(S, S), pretrained=False, freeze_ratio=1.0, dropout=0.0,
+                        compute_dtype=dtype, stochastic_depth_prob=0.0)
+    assert prod.use_rope and prod.model.rope_cfg is None
+    prod.load_state_dict({k: v.float() for k, v in orc.state_dict().items()})
+    prod = prod.cuda().float()
+    x = _make_video(B, N, T, S, seed=5)
+    ref = orc(x.double())
+    out, tokens = prod(x.cuda(), return_tokens=True)
+    assert tokens.shape == (B, N, 512)  # N clips x L = 1 token each
+    assert out.shape == ref.shape == (B, 512)
+    assert _rel(out.cpu(), ref) < tol, _rel(out.cpu(), ref)
+    g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1)).double()
+    ref.backward(g)
+    out.backward(g.float().cuda())
+    _grad_check(prod, orc, {"rel_pos": gtol * 4}, gtol, 1e-2 if dtype == torch.float32 else 5e-2)
