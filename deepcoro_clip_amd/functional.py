@@ -464,6 +464,82 @@ def mlp(x, w1, b1, w2, b2, residual=None):
     return MlpFn.apply(x, w1, b1, w2, b2, residual)
 
 
+def wpack_mlp(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """The fused MLP kernel's weight image of (fc1.weight, fc2.weight), cached on fc1's parameter like the bf16 shadows and valid
+    for one (autograd versions, optimizer epoch) pair: one small repack launch per MLP and step."""
+    cache = w1.__dict__.setdefault("_dcc_mlp_pack", {})
+    stamp = (w1._version, w2._version, _WEPOCH, w1.data_ptr(), w2.data_ptr())
+    hit = cache.get("p")
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    t = K.mlp_pack(wcast(w1, torch.bfloat16), wcast(w2, torch.bfloat16))
+    cache["p"] = (stamp, t)
+    return t
+
+
+FUSED_MLP = os.environ.get("DCC_FUSED_MLP", "1") != "0"   # A/B switch: 0 = LayerNorm + two GEMMs
+
+
+def ln_mlp_ok(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
+    C = x.shape[-1]
+    return (FUSED_MLP and x.dtype == torch.bfloat16 and not _FP8["on"] and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
+            and w1.dtype == torch.float32 and w1.is_contiguous() and w2.is_contiguous() and K.mlp_fused_channels(C))
+
+
+class LnMlpFn(torch.autograd.Function):
+    """y = [x +] fc2(gelu(fc1(LayerNorm(x)))): the second half of an MViT block (torchvision MultiscaleBlock, reached through
+    models/video_encoder.py:232-253) as ONE forward launch (csrc/mlp_fused.hip).  The backward is the unfused one: the kernel
+    saved LayerNorm(x), the statistics, the pre-activation and the activation."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w1, b1, w2, b2, eps, residual):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        save = any(ctx.needs_input_grad)
+        y, xn, mean, rstd, pre, act = K.ln_mlp_fwd(x2, gamma.detach(), beta.detach(), eps, wpack_mlp(w1, w2), b1.detach(),
+                                                  b2.detach(), residual=residual, save=save)
+        if save:
+            ctx.save_for_backward(x2, xn, mean, rstd, gamma.detach(), wcast(w1, x.dtype), wcast(w2, x.dtype), pre, act)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.residual = residual
+        ctx.xshape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xn, mean, rstd, gamma, w1c, w2c, pre, act = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        Hd, C = w1c.shape
+        dy2 = _as_dtype(_c(dy).reshape(-1, C), x2.dtype)
+        dw1 = db1 = dw2 = db2 = None
+        if ctx.needs_input_grad[5]:
+            db2 = _grad_slots.take(b2) if ctx.needs_input_grad[6] else None
+            if db2 is None and ctx.needs_input_grad[6]:
+                db2 = zeros_f32(C, dy2.device)
+            dw2 = wgrad(dy2, act, db2, side=WGRAD_SIDE and grads_unset(w2, b2), out=_grad_slots.take(w2))
+        elif ctx.needs_input_grad[6]:
+            db2 = K.colsum(dy2)
+        dpre = _dx_gemm(dy2, w2, w2c, dgelu=True, aux=pre)
+        if ctx.needs_input_grad[3]:
+            db1 = _grad_slots.take(b1) if ctx.needs_input_grad[4] else None
+            if db1 is None and ctx.needs_input_grad[4]:
+                db1 = zeros_f32(Hd, dy2.device)
+            dw1 = wgrad(dpre, xn, db1, side=WGRAD_SIDE and grads_unset(w1, b1), out=_grad_slots.take(w1))
+        elif ctx.needs_input_grad[4]:
+            db1 = K.colsum(dpre)
+        dx = dg = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dxn = _dx_gemm(dpre, w1, w1c)
+            dgb = zeros_f32((2, C), x2.device)
+            dx = K.layernorm_bwd(dxn, x2, mean, rstd, gamma, dgb[0], dgb[1], dres=dy2 if ctx.residual else None).reshape(ctx.xshape)
+            dg, db = dgb[0], dgb[1]
+        return dx, dg, db, dw1, db1, dw2, db2, None, None
+
+
+def ln_mlp(x, gamma, beta, w1, b1, w2, b2, eps: float, residual: bool = True):
+    return LnMlpFn.apply(x, gamma, beta, w1, b1, w2, b2, eps, residual)
+
+
 # ---------------------------------------------------------------------------------- LayerNorm
 class LayerNormFn(torch.autograd.Function):
     @staticmethod

@@ -285,6 +285,50 @@ def layernorm_fwd(x2d: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ep
     return out, mean, rstd
 
 
+# --------------------------------------------------------------------- fused LayerNorm + MLP (csrc/mlp_fused.hip)
+def mlp_fused_channels(C: int) -> bool:
+    return L.lib().dcc_mlp_packed_bytes(int(C)) > 0
+
+
+def mlp_pack(w1c: torch.Tensor, w2c: torch.Tensor) -> torch.Tensor:
+    """bf16 fc1 weight [4C, C] and fc2 weight [C, 4C] -> the fused kernel's stream image (MFMA-fragment order)."""
+    L.require_cuda(w1c, w2c)
+    C = w1c.shape[1]
+    assert w1c.dtype == torch.bfloat16 and w2c.dtype == torch.bfloat16 and w1c.is_contiguous() and w2c.is_contiguous()
+    assert w1c.shape == (4 * C, C) and w2c.shape == (C, 4 * C)
+    nbytes = L.lib().dcc_mlp_packed_bytes(C)
+    if nbytes <= 0:
+        raise L.DccError(f"dcc_mlp_pack_weights: C = {C} is outside the fused MLP kernel's domain")
+    out = torch.empty(nbytes // 2, device=w1c.device, dtype=torch.bfloat16)
+    L.call("dcc_mlp_pack_weights", L.ptr(w1c), L.ptr(w2c), L.ptr(out), C, L.stream())
+    return out
+
+
+def ln_mlp_fwd(x2d: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, packed: torch.Tensor, b1: torch.Tensor,
+               b2: torch.Tensor, residual: bool = True, save: bool = True, save_act: bool = True):
+    """y = [x +] fc2(gelu(fc1(LayerNorm(x)))) in one launch.  Returns (y, xn, mean, rstd, pre, act); the last five are None
+    without `save` (inference), `act` is None without `save_act`."""
+    L.require_cuda(x2d, gamma, beta, packed, b1, b2)
+    M, C = x2d.shape
+    assert x2d.dtype == torch.bfloat16 and x2d.stride(1) == 1
+    dev = x2d.device
+    y = torch.empty((M, C), device=dev, dtype=torch.bfloat16)
+    xn = mean = rstd = pre = act = None
+    if save:
+        xn = torch.empty((M, C), device=dev, dtype=torch.bfloat16)
+        mean = torch.empty(M, device=dev, dtype=torch.float32)
+        rstd = torch.empty(M, device=dev, dtype=torch.float32)
+        pre = torch.empty((M, 4 * C), device=dev, dtype=torch.bfloat16)
+        if save_act:
+            act = torch.empty((M, 4 * C), device=dev, dtype=torch.bfloat16)
+    nbytes = 2.0 * M * C * (2 + (1 if save else 0) + (4 if save else 0) + (4 if act is not None else 0)) + packed.numel() * 2.0
+    with _timed("gemm_bf16", 16.0 * M * C * C, lambda: f"ln_mlp M{M} C{C}", nbytes):
+        L.call("dcc_ln_mlp_fwd", L.ptr(x2d), x2d.stride(0), L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(packed), L.ptr(b1),
+               L.ptr(b2), L.ptr(y), y.stride(0), L.ptr(xn), L.ptr(mean), L.ptr(rstd), L.ptr(pre), L.ptr(act), M, C,
+               int(bool(residual)), L.stream())
+    return y, xn, mean, rstd, pre, act
+
+
 _LN_WS: dict = {}
 
 

@@ -167,6 +167,10 @@ class _Block(nn.Module):
             x = Fn.stochastic_depth_add(xs, Fn.linear(att, a.project[0].weight, a.project[0].bias), self.sd_prob, Bp)
         else:
             x = Fn.linear(att, a.project[0].weight, a.project[0].bias, residual=xs)
+        if Fn.ln_mlp_ok(x, self.mlp[0].weight, self.mlp[3].weight):   # norm2 + fc1 + GELU + fc2 (+ residual) as one launch
+            y = Fn.ln_mlp(x, self.norm2.weight, self.norm2.bias, self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight,
+                          self.mlp[3].bias, self.eps, residual=not drop)
+            return Fn.stochastic_depth_add(x, y, self.sd_prob, Bp) if drop else y
         xn2, x = Fn.layernorm_skip(x, self.norm2.weight, self.norm2.bias, self.eps)  # x also is the MLP's residual
         if drop:
             return Fn.stochastic_depth_add(x, Fn.mlp(xn2, self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight,

@@ -130,6 +130,21 @@ int dcc_relpos_aug_bwd_ln(const void* dQf, const void* Qf, void* dconv, const vo
                           float scale, const void* conv, const float* mean, const float* rstd, const float* gamma, float* dgamma,
                           float* dbeta, int dtype, void* stream);
 
+/* ---- fused MLP forward of an MViT block (csrc/mlp_fused.hip): y = [x +] fc2(gelu(fc1(LayerNorm(x)))), hidden = 4 C --------
+ * torchvision MultiscaleBlock's `x = x + mlp(norm2(x))` (reached through models/video_encoder.py:232-253) in ONE launch: the
+ * [M, 4C] hidden tensor is produced and consumed in registers and only streams out for the backward.  bf16, C in {96, 192, 384}.
+ *   packed   = dcc_mlp_pack_weights(w1 [4C, C], w2 [C, 4C], both row-major bf16): the two weights in MFMA-fragment order,
+ *              dcc_mlp_packed_bytes(C) bytes (0: C outside the domain); re-pack whenever the weights change
+ *   y [M, C] (row pitch ldy) = (residual ? x : 0) + b2 + W2 gelu(bf16(W1 LN(x) + b1)); LN statistics in fp32
+ *   saved for the backward (each nullable): xn [M, C] = LayerNorm(x), mean / rstd [M] fp32, pre [M, 4C] = bf16(fc1 + b1),
+ *   act [M, 4C] = gelu(pre) (act != NULL needs pre != NULL).
+ * DCC_ERR_UNSUPPORTED outside the domain: use dcc_layernorm_fwd + dcc_gemm (the two-GEMM path). */
+int dcc_mlp_packed_bytes(int C);
+int dcc_mlp_pack_weights(const void* w1, const void* w2, void* packed, int C, void* stream);
+int dcc_ln_mlp_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* packed,
+                   const float* b1, const float* b2, void* y, int64_t ldy, void* xn, float* mean, float* rstd, void* pre,
+                   void* act, int64_t M, int C, int residual, void* stream);
+
 /* ---- LayerNorm (csrc/norm.hip): nn.LayerNorm in MViT blocks / Pool.norm_act / BERT / aggregator /
  * attention pool (models/video_aggregator.py:15,24,99; models/attention_pool.py:53,94). */
 int dcc_layernorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
