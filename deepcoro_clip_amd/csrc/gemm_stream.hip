@@ -188,7 +188,9 @@ __global__ __launch_bounds__(SNT, MINW) void gemm_stream_kernel(GemmParams p, St
                 for (int P = 0; P < 2; ++P)
                   *reinterpret_cast<u32x4*>(stg_w + 64 * j + 32 * P) = (pass == 0 && (F & GEMM_SAVE_PRE)) ? cpre[j][P] : cfin[j][P];
             }
+            asm volatile("" ::: "memory");   // cross-lane exchange through LDS: no per-thread reasoning about these bytes (csrc/mlp_fused.hip)
             const u32x4 o = *reinterpret_cast<const u32x4*>(stg_r);
+            asm volatile("" ::: "memory");
             const int srow = srow0 + 8 * q;
             if (geo.dbg & 1) asm volatile("" ::"v"(o));
             else if (srow < p.M) *reinterpret_cast<u32x4*>(base + (int64_t)srow * ld + scol) = o;

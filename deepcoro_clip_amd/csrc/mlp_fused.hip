@@ -24,6 +24,15 @@
 
 namespace {
 
+#ifdef DCC_MLP_PROFILE   // phase timers (tools/mlp_profile.py; never in the shipped library)
+__device__ unsigned long long g_mprof[8];  // [0] vmcnt wait [1] barrier [2] GEMM1 + DMA issue [3] GEMM2 || epilogue [4] swaps + stores [5] iterations [6] tile head [7] y store
+#define MPROF_T() __builtin_amdgcn_s_memtime()
+#define MPROF_ADD(i, v) mprof[i] += (unsigned long long)(v)
+#else
+#define MPROF_T() 0ull
+#define MPROF_ADD(i, v) do { } while (0)
+#endif
+
 struct MlpParams {
   const bf16_t* x;
   int64_t ldx;
@@ -56,10 +65,31 @@ __device__ __forceinline__ float lo_f(uint32_t u) { return __builtin_bit_cast(fl
 __device__ __forceinline__ float hi_f(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
 constexpr int MSTG_PITCH = 144;                // strip rows: 128 bytes + 16
-constexpr int MSTG_WAVE = 8 * MSTG_PITCH;      // per wave: 8 rows x 64 columns
 
-// C: channels (96 | 192 | 384); NW: waves per workgroup; HS: hidden units per ring stage (32 | 64); MINW: waves per SIMD
-template <int C, int NW, int HS, int MINW>
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+// An MFMA A fragment read into ACCUMULATOR registers by hand (the compiler neither counts nor waits for it: mlds_wait below).  Why: an
+// in-flight MFMA keeps reading its A / B registers, and hipcc hands a fragment's VGPRs to the next vector instruction's result as soon
+// as the MFMA has issued — the write then stalls until the MFMA is done (measured: +47 cycles per MFMA, nothing of the epilogue's
+// vector work overlapped).  Vector instructions cannot target AGPRs, so fragments kept there are never in their way.
+template <int OFF>
+__device__ __forceinline__ bf16x8 mlds_read_a(uint32_t addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void mlds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+// C: channels (96 | 192 | 384); NW: waves per workgroup; HS: hidden units per ring stage (32 | 64); MINW: waves per SIMD;
+// SR: rows of a wave's store-staging strip (32: a whole row tile per LDS round trip; 16 where the ring leaves no room)
+// HAND: GEMM2 || epilogue placed instruction group by instruction group (one wave per SIMD: nothing else hides the vector work);
+// else eight compiler-scheduled groups (two waves per SIMD cover each other: measured faster at C = 96)
+template <int C, int NW, int HS, int MINW, int SR, bool HAND>
 __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
   constexpr int HID = 4 * C, KS = C / 16, MT = C / 32, U = HS / 32, NC = HID / 32;
   constexpr int HALF = 64 * C;                 // bytes of one packed W1 (or W2) tile of 32 hidden units
@@ -68,23 +98,30 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
   constexpr int NSTG = 3;
   constexpr int NSTT = (NC + U) / U;           // stages per row tile (sub-slots 0 .. NC)
   constexpr int NT = NW * 64;
-  static_assert(NPIECE % NW == 0 && (NC % 2) == 0, "geometry");
+  static_assert(NPIECE % NW == 0 && (NC % 2) == 0 && 2 * PW == KS, "geometry");
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
   float* b1_l = reinterpret_cast<float*>(lds + NSTG * STAGE);
+  constexpr bool CONST_LDS = SR == 32;   // b2 / gamma / beta in LDS (else straight from global: once per row tile)
   float* b2_l = b1_l + HID;
   float* gam_l = b2_l + C;
   float* bet_l = gam_l + C;
-  char* stg = reinterpret_cast<char*>(bet_l + C) + wave * MSTG_WAVE;
+  constexpr int STG_WAVE = SR * MSTG_PITCH;
+  char* stg = reinterpret_cast<char*>(CONST_LDS ? bet_l + C : b1_l + HID) + wave * STG_WAVE;
   for (int i = tid; i < HID; i += NT) b1_l[i] = p.b1[i];
-  for (int i = tid; i < C; i += NT) {
-    b2_l[i] = p.b2[i];
-    gam_l[i] = p.gamma[i];
-    bet_l[i] = p.beta[i];
+  if constexpr (CONST_LDS) {
+    for (int i = tid; i < C; i += NT) {
+      b2_l[i] = p.b2[i];
+      gam_l[i] = p.gamma[i];
+      bet_l[i] = p.beta[i];
+    }
   }
+  const float* b2_s = CONST_LDS ? b2_l : p.b2;
+  const float* gam_s = CONST_LDS ? gam_l : p.gamma;
+  const float* bet_s = CONST_LDS ? bet_l : p.beta;
   __syncthreads();
 
   // ------------------------------------------------------------------------------------------- weight stream
@@ -105,11 +142,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
     for (int j = 0; j < PW; ++j) issue_piece(j);
     issue_done();
   }
+#ifdef DCC_MLP_PROFILE
+  unsigned long long mprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   int cur_slot = NSTG - 1;   // advanced before use
   int issued = 0;            // stage advances so far (0, 1: the ring is still filling, fewer stores are in flight)
 
-  // staging addresses: this lane WRITES row r & 7 (in pass r >> 3) at byte 64 j + 32 P + 16 h, READS row lane >> 3 at byte 16 (lane & 7)
-  char* stg_w = stg + (r & 7) * MSTG_PITCH + 16 * h;
+  // staging addresses: this lane WRITES row r % SR (in pass r / SR) at byte 64 j + 32 P + 16 h, READS rows lane / 8 + 8 k at byte 16 (lane & 7)
+  char* stg_w = stg + (r % SR) * MSTG_PITCH + 16 * h;
   const char* stg_r = stg + (lane >> 3) * MSTG_PITCH + 16 * (lane & 7);
 
   for (int t0 = blockIdx.x * NW; t0 < p.tiles; t0 += gridDim.x * NW) {
@@ -126,19 +166,29 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
     auto store_pair = [&](bf16_t* base, int64_t ld, int col0, const u32x4 (&c)[2][2], bool nt) {
       const int scol = col0 + 8 * (lane & 7);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if ((r >> 3) == q) {
+      for (int q = 0; q < 32 / SR; ++q) {   // one LDS round trip per SR rows: all their lanes write, then SR / 8 reads + stores
+        if (SR == 32 || (r / SR) == q) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int P = 0; P < 2; ++P) *reinterpret_cast<u32x4*>(stg_w + 64 * j + 32 * P) = c[j][P];
         }
-        const u32x4 o = *reinterpret_cast<const u32x4*>(stg_r);
-        const int srow = srow0 + 8 * q;
-        if (srow < p.M) {
-          u32x4* dst = reinterpret_cast<u32x4*>(base + (int64_t)srow * ld + scol);
-          if (nt) __builtin_nontemporal_store(o, dst);
-          else *dst = o;
+        // lanes exchange data through the strip: the compiler must not reason about these bytes per thread (it otherwise keeps a
+        // lane's EARLIER read of the same address when that lane's own writes were masked off); the hardware runs a wave's LDS
+        // operations in order, so a compiler-level barrier is all the ordering this needs
+        asm volatile("" ::: "memory");
+        u32x4 o[SR / 8];
+#pragma unroll
+        for (int k = 0; k < SR / 8; ++k) o[k] = *reinterpret_cast<const u32x4*>(stg_r + 8 * k * MSTG_PITCH);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < SR / 8; ++k) {
+          const int srow = srow0 + SR * q + 8 * k;
+          if (srow < p.M) {
+            u32x4* dst = reinterpret_cast<u32x4*>(base + (int64_t)srow * ld + scol);
+            if (nt) __builtin_nontemporal_store(o[k], dst);
+            else *dst = o[k];
+          }
         }
       }
     };
@@ -153,6 +203,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
     };
 
     // ----------------------------------------------------------------------------------- x, LayerNorm, Y init
+    const unsigned long long tp0 = MPROF_T();
     u32x4 xf[KS];   // raw x, then LayerNorm(x): this lane's row, channels 16 s + 8 h .. + 7
     {
       const bf16_t* xr = p.x + lrow * p.ldx + 8 * h;
@@ -173,7 +224,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
           const int g = 2 * gp + o;
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(b2_l + 32 * mt + 8 * g + 4 * h);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(b2_s + 32 * mt + 8 * g + 4 * h);
           const uint32_t e_ = o ? e[1] : e[0], f_ = o ? f[1] : f[0];
           const float rs_ = p.residual ? 1.0f : 0.0f;
           Y[mt][4 * g + 0] = b4[0] + rs_ * lo_f(e_);
@@ -207,8 +258,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
       }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam_l + 16 * s + 8 * h), g1 = *reinterpret_cast<const f32x4*>(gam_l + 16 * s + 8 * h + 4);
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(bet_l + 16 * s + 8 * h), c1 = *reinterpret_cast<const f32x4*>(bet_l + 16 * s + 8 * h + 4);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam_s + 16 * s + 8 * h), g1 = *reinterpret_cast<const f32x4*>(gam_s + 16 * s + 8 * h + 4);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(bet_s + 16 * s + 8 * h), c1 = *reinterpret_cast<const f32x4*>(bet_s + 16 * s + 8 * h + 4);
         u32x4 o;
         o[0] = mpack2((lo_f(xf[s][0]) - mean) * rstd * g0[0] + c0[0], (hi_f(xf[s][0]) - mean) * rstd * g0[1] + c0[1]);
         o[1] = mpack2((lo_f(xf[s][1]) - mean) * rstd * g0[2] + c0[2], (hi_f(xf[s][1]) - mean) * rstd * g0[3] + c0[3]);
@@ -229,6 +280,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
       }
     }
 
+    MPROF_ADD(6, MPROF_T() - tp0);
     // --------------------------------------------------------------------------------------------- main loop
     f32x16 acc;
     u32x4 actf[2][2];     // [parity of the hidden tile][k-step]: gelu(pre) packed = B fragments of GEMM2
@@ -237,6 +289,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
 
     // the next stage of the stream becomes readable (its refill pieces go out between the MFMAs of GEMM1 below)
     auto advance = [&]() {
+      const unsigned long long ta0 = MPROF_T();
       if (issued >= 2 && exact) {
         // younger than this stage's DMA: the next stage's PW pieces + the output stores of the two iterations in between
         if (p.act != nullptr) mwait_vm<PW + (U == 2 ? 16 : 8)>();
@@ -245,7 +298,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
       } else {
         mwait_vm<PW>();
       }
+      const unsigned long long ta1 = MPROF_T();
       __builtin_amdgcn_s_barrier();
+      MPROF_ADD(0, ta1 - ta0);
+      MPROF_ADD(1, MPROF_T() - ta1);
       cur_slot = cur_slot + 1 == NSTG ? 0 : cur_slot + 1;
       ++issued;
     };
@@ -260,39 +316,103 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
         sub = lds + cur_slot * STAGE;
       }
       const char* ss = sub + ((U == 2 && E == 1) ? SUBB : 0) + lane * 16;
+      const unsigned long long tb0 = MPROF_T();
+      // Both GEMM phases are written plainly and ORDERED by scheduling groups (cdna guide T19): one MFMA per group, and in its shadow
+      // the operand read of a later MFMA plus a share of the phase's other work (LDS-DMA issues in GEMM1, the epilogue's vector
+      // instructions in GEMM2).  An in-order wave that issues MFMAs back to back stalls on the second one: the work must sit BETWEEN them.
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (G1) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1_l + 32 * i + 8 * g + 4 * h);
           acc[4 * g] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
         }
-        constexpr int CH = (KS % 4 == 0) ? 4 : 3, NCH = KS / CH;
-        bf16x8 fa[2][CH];
+        // source order = issue order: an LDS-DMA writes LDS, so the compiler keeps it between the operand reads it was written between
+        constexpr int AHEAD = 3;                                // operand reads in flight ahead of their MFMA
+        bf16x8 wf[AHEAD + 1];
 #pragma unroll
-        for (int e = 0; e < CH; ++e) fa[0][e] = *reinterpret_cast<const bf16x8*>(ss + HALF + e * 1024);
+        for (int s = 0; s < AHEAD; ++s) wf[s] = *reinterpret_cast<const bf16x8*>(ss + HALF + s * 1024);
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          if (c + 1 < NCH) {
+        for (int s = 0; s < KS; ++s) {
+          if (s + AHEAD < KS) wf[(s + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const bf16x8*>(ss + HALF + (s + AHEAD) * 1024);
+          if (ADV && (s & 1)) issue_piece(s >> 1);               // PW == KS / 2: a DMA piece behind every other MFMA
+          acc = mma16(wf[s % (AHEAD + 1)], __builtin_bit_cast(bf16x8, xf[s]), acc);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + AHEAD, 0);
 #pragma unroll
-            for (int e = 0; e < CH; ++e) fa[(c + 1) & 1][e] = *reinterpret_cast<const bf16x8*>(ss + HALF + ((c + 1) * CH + e) * 1024);
-          }
-          if constexpr (ADV) {
-#pragma unroll
-            for (int j = c * PW / NCH; j < (c + 1) * PW / NCH; ++j) issue_piece(j);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int e = 0; e < CH; ++e) acc = mma16(fa[c & 1][e], __builtin_bit_cast(bf16x8, xf[c * CH + e]), acc);
+        for (int s = 0; s < KS; ++s) {
+          if (s + AHEAD < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (ADV && (s & 1)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
       } else if constexpr (ADV) {
 #pragma unroll
         for (int j = 0; j < PW; ++j) issue_piece(j);
       }
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (ADV) issue_done();
-      {
+      const unsigned long long tb1 = MPROF_T();
+      MPROF_ADD(2, tb1 - tb0);
+      MPROF_ADD(5, 1);
+      uint32_t pk[8], ak[8];
+      if constexpr (HAND) {
+        // GEMM2(i-1) with the epilogue of tile i cut into 24 parts (8 register pairs x {round + polynomial, exp / rcp, pack}) placed
+        // by hand between the MFMAs; the W2 fragments come through AGPRs (mlds_read_a), AHEAD reads in flight
+        constexpr int NM2 = 2 * MT, AHEAD = 3, NPART = 24;
+        float gx[2], gu[2];
+        bf16x8 w2f[AHEAD + 1];
+        const uint32_t a2 = (uint32_t)(uintptr_t)LDS_PTR(const char, ss);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (G2) {
+          static_for<AHEAD>([&](auto mc) { constexpr int m = decltype(mc)::value; w2f[m] = mlds_read_a<m * 1024>(a2); });
+        }
+        static_for<NPART>([&](auto pc) {
+          constexpr int P = decltype(pc)::value;
+          if constexpr (G2) {
+            static_for<NM2>([&](auto mc) {
+              constexpr int m = decltype(mc)::value;
+              if constexpr (m * NPART / NM2 == P) {
+                if constexpr (m + AHEAD < NM2) w2f[(m + AHEAD) % (AHEAD + 1)] = mlds_read_a<(m + AHEAD) * 1024>(a2);
+                mlds_wait<(m + AHEAD < NM2) ? AHEAD : NM2 - 1 - m>();
+                __builtin_amdgcn_sched_barrier(0);
+                Y[m >> 1] = mma16(w2f[m % (AHEAD + 1)], __builtin_bit_cast(bf16x8, actf[E ^ 1][m & 1]), Y[m >> 1]);
+              }
+            });
+          }
+          if constexpr (G1) {
+            // round the pre-activation once (what the unfused bf16 Linear hands to GELU), GELU on the rounded value:
+            // gelu(x) = x / (1 + exp2(x (c1 + c2 x^2)))   (gelu_bf16 of common.h with the exponent's scale folded into c1, c2)
+            constexpr int q = P / 3, k = P % 3;
+            if constexpr (k == 0) {
+              pk[q] = mpack2(acc[2 * q], acc[2 * q + 1]);
+              gx[0] = lo_f(pk[q]);
+              gx[1] = hi_f(pk[q]);
+#ifdef DCC_EXACT_GELU
+              gu[0] = gelu_f(gx[0]);
+              gu[1] = gelu_f(gx[1]);
+#else
+              gu[0] = gx[0] * (-2.30876515f - 0.10012561f * gx[0] * gx[0]);
+              gu[1] = gx[1] * (-2.30876515f - 0.10012561f * gx[1] * gx[1]);
+#endif
+            } else if constexpr (k == 1) {
+#ifndef DCC_EXACT_GELU
+              gu[0] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gu[0]));
+              gu[1] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gu[1]));
+#endif
+            } else {
+#ifdef DCC_EXACT_GELU
+              ak[q] = mpack2(gu[0], gu[1]);
+#else
+              ak[q] = mpack2(gx[0] * gu[0], gx[1] * gu[1]);
+#endif
+              asm volatile("" : "+v"(ak[q]));   // needed only an iteration later: without a use here the compiler sinks the work out
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
         constexpr int NM2 = 2 * MT, PER = (NM2 + 7) / 8;
         bf16x8 fb[2][PER];
-        uint32_t pk[8], ak[8];
         auto lo = [](int q) { return q * NM2 / 8; };
         if constexpr (G2) {
 #pragma unroll
@@ -311,12 +431,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
               Y[m >> 1] = mma16(fb[q & 1][m - lo(q)], __builtin_bit_cast(bf16x8, actf[E ^ 1][m & 1]), Y[m >> 1]);
           }
           if constexpr (G1) {
-            // round the pre-activation once (what the unfused bf16 Linear hands to GELU), GELU on the rounded value
             pk[q] = mpack2(acc[2 * q], acc[2 * q + 1]);
             ak[q] = mpack2(gelu_for<bf16_t>(lo_f(pk[q])), gelu_for<bf16_t>(hi_f(pk[q])));
+            asm volatile("" : "+v"(ak[q]));
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+      }
+      {
+        const unsigned long long tb2 = MPROF_T();
+        MPROF_ADD(3, tb2 - tb1);
         if constexpr (G1) {
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
@@ -345,6 +469,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
             }
           }
         }
+        MPROF_ADD(4, MPROF_T() - tb2);
       }
     };
     using T0 = std::integral_constant<int, 0>;
@@ -360,6 +485,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
     body(NC, T0{}, No{}, Yes{});
 
     // ------------------------------------------------------------------------------------------------ y
+    const unsigned long long ty0 = MPROF_T();
     if (tile_live) {
       u32x4 cy[2][2];
 #pragma unroll
@@ -377,8 +503,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void ln_mlp_kernel(MlpParams p) {
         else if (mt == MT - 1) store_single(p.y, p.ldy, 32 * mt, cy[0], false);
       }
     }
+    MPROF_ADD(7, MPROF_T() - ty0);
   }
   mwait_vm<0>();   // LDS-DMA pieces still in flight must land before the workgroup's LDS is handed on
+#ifdef DCC_MLP_PROFILE
+  if (lane == 0 && wave == 0) {
+    for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_mprof[i_], mprof[i_]);
+  }
+#endif
 }
 
 // w1 [4C, C], w2 [C, 4C] (row-major bf16) -> the stream image: NSTT * STAGE bytes; sub-slot i (128 C bytes) = [W2 tile i-1 | W1 tile i],
@@ -421,9 +553,9 @@ __global__ void mlp_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __r
 }
 
 template <int C> struct MlpCfg;
-template <> struct MlpCfg<96> { static constexpr int NW = 8, HS = 64, MINW = 2; };
-template <> struct MlpCfg<192> { static constexpr int NW = 4, HS = 64, MINW = 1; };
-template <> struct MlpCfg<384> { static constexpr int NW = 4, HS = 32, MINW = 1; };
+template <> struct MlpCfg<96> { static constexpr int NW = 8, HS = 64, MINW = 2, SR = 32; static constexpr bool HAND = false; };
+template <> struct MlpCfg<192> { static constexpr int NW = 4, HS = 32, MINW = 1, SR = 32; static constexpr bool HAND = true; };
+template <> struct MlpCfg<384> { static constexpr int NW = 4, HS = 32, MINW = 1, SR = 16; static constexpr bool HAND = true; };
 
 template <int C> constexpr int mlp_stages() { return (4 * C / 32 + MlpCfg<C>::HS / 32) / (MlpCfg<C>::HS / 32); }
 template <int C> constexpr int mlp_stage_bytes() { return (MlpCfg<C>::HS / 32) * 128 * C; }
@@ -431,9 +563,9 @@ template <int C> constexpr int mlp_stage_bytes() { return (MlpCfg<C>::HS / 32) *
 template <int C>
 int mlp_launch(const MlpParams& p, hipStream_t st) {
   using Cfg = MlpCfg<C>;
-  constexpr int LDS = 3 * mlp_stage_bytes<C>() + (4 * C + 3 * C) * 4 + Cfg::NW * MSTG_WAVE;
+  constexpr int LDS = 3 * mlp_stage_bytes<C>() + (4 * C + (Cfg::SR == 32 ? 3 * C : 0)) * 4 + Cfg::NW * Cfg::SR * MSTG_PITCH;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = ln_mlp_kernel<C, Cfg::NW, Cfg::HS, Cfg::MINW>;
+  auto kern = ln_mlp_kernel<C, Cfg::NW, Cfg::HS, Cfg::MINW, Cfg::SR, Cfg::HAND>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DCC_ERR_LAUNCH;
   int per_cu = (160 * 1024) / LDS;
   if (per_cu > 1) per_cu = 1;   // one ring per CU: the workgroup's waves already fill the SIMDs to MINW
@@ -445,6 +577,13 @@ int mlp_launch(const MlpParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef DCC_MLP_PROFILE
+extern "C" int dcc_mlp_profile(unsigned long long* out, int reset) {  // debug builds only (-DDCC_MLP_PROFILE)
+  if (reset) { unsigned long long z[8] = {0}; return hipMemcpyToSymbol(HIP_SYMBOL(g_mprof), z, sizeof(z)) == hipSuccess ? 0 : -1; }
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mprof), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Size in bytes of the packed image for `C` channels (0: C outside the kernel's domain).
 extern "C" int dcc_mlp_packed_bytes(int C) {

@@ -477,13 +477,17 @@ def wpack_mlp(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     return t
 
 
-FUSED_MLP = os.environ.get("DCC_FUSED_MLP", "1") != "0"   # A/B switch: 0 = LayerNorm + two GEMMs
+# Which channel counts take the fused LayerNorm + MLP forward kernel.  Measured at the tower's shapes (tools/mlp_bench.py, 32 clips):
+# C = 96 362 vs 584 us (at the HBM roofline of the tensors it must write), C = 192 263 vs 348 us; C = 384 is not there yet (one wave
+# per SIMD cannot cover its own epilogue: 243-258 vs 195-212 us) and stays on LayerNorm + two GEMMs.  DCC_FUSED_MLP = 0 | 1 | all.
+_FUSED_MLP_ENV = os.environ.get("DCC_FUSED_MLP", "1")
+FUSED_MLP_CHANNELS = () if _FUSED_MLP_ENV == "0" else ((96, 192, 384) if _FUSED_MLP_ENV == "all" else (96, 192))
 
 
 def ln_mlp_ok(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
     C = x.shape[-1]
-    return (FUSED_MLP and x.dtype == torch.bfloat16 and not _FP8["on"] and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
-            and w1.dtype == torch.float32 and w1.is_contiguous() and w2.is_contiguous() and K.mlp_fused_channels(C))
+    return (C in FUSED_MLP_CHANNELS and x.dtype == torch.bfloat16 and not _FP8["on"] and w1.shape == (4 * C, C)
+            and w2.shape == (C, 4 * C) and w1.dtype == torch.float32 and w1.is_contiguous() and w2.is_contiguous())
 
 
 class LnMlpFn(torch.autograd.Function):

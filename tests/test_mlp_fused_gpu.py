@@ -137,7 +137,7 @@ def test_autograd_node_matches_the_unfused_nodes(C, residual):
     dy = torch.randn(M, C, generator=g).bfloat16().cuda()
     xa, xb = x0.cuda().requires_grad_(True), x0.cuda().requires_grad_(True)
     pa, pb = params(), params()
-    assert Fn.ln_mlp_ok(xa, pa[2], pa[4])
+    assert Fn.ln_mlp_ok(xa, pa[2], pa[4]) == (C in Fn.FUSED_MLP_CHANNELS)
     ya = Fn.ln_mlp(xa, pa[0], pa[1], pa[2], pa[3], pa[4], pa[5], 1e-6, residual=residual)
     ya.backward(dy)
     xn, xs = Fn.layernorm_skip(xb, pb[0], pb[1], 1e-6)
