@@ -168,6 +168,14 @@ __device__ __forceinline__ uint32_t hash32(uint64_t k) {
   return (uint32_t)(k >> 32);
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) holds per DEVICE: the launchers remember it in a bit per device, not in one
+// process-wide flag (a second GPU driven by the same process would otherwise launch its 150 KB kernels unconfigured).
+static inline unsigned long long dcc_dev_bit() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return 1ull << (dev & 63);
+}
+
 static inline int dcc_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DCC_OK : DCC_ERR_LAUNCH;

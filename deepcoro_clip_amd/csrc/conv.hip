@@ -218,10 +218,11 @@ bool launch_im2col_row(const TI* x, bf16_t* col, Im2colGeom g, const float* mean
   const int64_t nrows_out = (int64_t)g.B * g.To * g.Ho;
   if (nrows_out >= (1LL << 31)) return false;
   auto kern = im2col3d_row_kernel<TI>;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  const unsigned long long devbit = dcc_dev_bit();
+  if (!(configured & devbit)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024) != hipSuccess) return false;
-    configured = true;
+    configured |= devbit;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nrows_out), dim3(256), lds, s, x, col, g, rg, mean, stdv);
   return true;
@@ -1663,7 +1664,8 @@ int launch_dw3_run(const void* x, void* y, const float* w, const PoolGeom& g, hi
   // runs of 7 output columns when the grid allows (56/28/14/7) and still leaves >= 2 waves per SIMD, else runs of 4
   const int64_t threads7 = (int64_t)g.B * g.H * g.To * g.Ho * ((g.Wo + 6) / 7) * cpr;
   bool w7 = (g.Wo % 7 == 0) && threads7 >= 131072;
-  if (const char* e = getenv("DCC_POOL_WT")) w7 = w7 && atoi(e) == 7;  // A/B knob for tools/pool_bench.py
+  static const int pool_wt = getenv("DCC_POOL_WT") ? atoi(getenv("DCC_POOL_WT")) : 0;  // A/B knob for tools/pool_bench.py (read once)
+  if (pool_wt) w7 = w7 && pool_wt == 7;
   RunGeom r = make_run_geom(g, vec, w7 ? 7 : 4);
   if (!set_spans(r, sizeof(TD), sizeof(T))) return DCC_ERR_UNSUPPORTED;  // caller falls back to the generic kernel
   const int items = r.runs + (g.has_cls ? g.B * g.H : 0);
@@ -1921,10 +1923,10 @@ extern "C" int dcc_dwconv_bwd_weight(const void* dy, const void* x, float* dw, f
 #define DW3K(KERN_, ...)                                                                                            \
   do {                                                                                                              \
     auto kern = KERN_;                                                                                              \
-    static bool cfg = false;                                                                                        \
-    if (!cfg) {                                                                                                     \
+    static unsigned long long cfg = 0;                                                                              \
+    if (!(cfg & dcc_dev_bit())) {                                                                                   \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess) return DCC_ERR_LAUNCH; \
-      cfg = true;                                                                                                   \
+      cfg |= dcc_dev_bit();                                                                                         \
     }                                                                                                               \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds3, s, __VA_ARGS__);                                       \
   } while (0)

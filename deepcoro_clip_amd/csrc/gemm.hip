@@ -633,6 +633,17 @@ extern "C" int dcc_gemm(const void* A, const void* B, void* C, const float* bias
     const int rc = dcc_gemm_stream_launch(p, st);
     if (rc != DCC_ERR_UNSUPPORTED) return rc;
   }
+  // Eight-phase 256 x 256 kernel (gemm_p8.hip) where it wins in the interleaved table (profiles/r03_p8_bench.txt, second run): the
+  // qkv projections — plain / bias epilogue, wide output, K = C — 57.8 vs 61.9 us at stage 2 (M 50208 N 1152 K 384), 53.1 vs 59.9 at
+  // stage 3 (M 12576 N 2304 K 768), and the plain N 1536 K 384 product 77.3 vs 82.7.  Its epilogue is not covered by anything (one
+  // workgroup per CU), so everything with a second output tensor or an activation stays on the 256 x 128 wide kernel.
+  static const int p8_mode = getenv("DCC_P8_GEMM") ? atoi(getenv("DCC_P8_GEMM")) : 1;   // A/B knob: 0 = never
+  if (p8_mode && in_dtype == DCC_BF16 && out_dtype == DCC_BF16 && aligned && variant == 0 && !a_km && !b_km && batch == 1 && splitk == 1 &&
+      !(flags & (GEMM_ACCUM | GEMM_COLSUM_A | GEMM_GELU | GEMM_DGELU | GEMM_SAVE_PRE | GEMM_RESID)) && M >= 8192 && N >= 1024 &&
+      K >= 384 && K <= 768) {
+    const int rc = dcc_gemm_p8_launch(p, st);
+    if (rc != DCC_ERR_UNSUPPORTED) return rc;
+  }
   // Measured on MI355X (tools/gemm_bench.py, profiles/r02_kernel_bench.txt): forward GEMMs with a short reduction and a
   // wide output (fc1: N = 4C, qkv: N = 3C; K = C <= 768) run 12-15 % faster on 256 x 256 tiles with 8 unspecialised
   // waves (half the L2 -> LDS operand traffic per FLOP) than on the ring kernel's 128 x 128 tiles; N = C outputs, k-major

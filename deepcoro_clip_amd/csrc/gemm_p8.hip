@@ -392,15 +392,16 @@ int dcc_gemm_p8_launch(const GemmParams& p, hipStream_t st) {
   else if (ef == (GEMM_BIAS | GEMM_GELU | GEMM_SAVE_PRE)) kern = gemm_p8_kernel<GEMM_BIAS | GEMM_GELU | GEMM_SAVE_PRE>;
   else if (ef == (GEMM_BIAS | GEMM_RESID)) kern = gemm_p8_kernel<GEMM_BIAS | GEMM_RESID>;
   else if (ef == GEMM_DGELU) kern = gemm_p8_kernel<GEMM_DGELU>;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  const unsigned long long devbit = dcc_dev_bit();
+  if (!(configured & devbit)) {
     for (const void* f : {reinterpret_cast<const void*>(gemm_p8_kernel<-1>), reinterpret_cast<const void*>(gemm_p8_kernel<0>),
                           reinterpret_cast<const void*>(gemm_p8_kernel<GEMM_BIAS>),
                           reinterpret_cast<const void*>(gemm_p8_kernel<GEMM_BIAS | GEMM_GELU | GEMM_SAVE_PRE>),
                           reinterpret_cast<const void*>(gemm_p8_kernel<GEMM_BIAS | GEMM_RESID>),
                           reinterpret_cast<const void*>(gemm_p8_kernel<GEMM_DGELU>)})
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS) != hipSuccess) return DCC_ERR_LAUNCH;
-    configured = true;
+    configured |= devbit;
   }
   int G = p8_cus() & ~7;
   if (G < 8) G = 8;

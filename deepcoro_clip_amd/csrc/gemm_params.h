@@ -42,6 +42,6 @@ int dcc_gemm_wide_launch(const GemmParams& p, int a_km, int b_km, int out_dtype,
 // Streaming panel kernel (gemm_stream.hip): row-major bf16 A [M,K] x W [N,K]^T -> bf16 with the weight resident in LDS, for the
 // early MViT blocks' short-reduction GEMMs (K in {96, 192, 288, 384, 576}, N % 32 == 0).  DCC_ERR_UNSUPPORTED outside its domain.
 int dcc_gemm_stream_launch(const GemmParams& p, hipStream_t stream);
-// Eight-phase 256 x 256 kernel (gemm_p8.hip, experimental: tuning variant 13 only): k-contiguous bf16 A [M,K], B [N,K] -> bf16,
+// Eight-phase 256 x 256 kernel (gemm_p8.hip; dispatched for the qkv projections of stages 2-3, variant 13 forces it): k-contiguous bf16 A [M,K], B [N,K] -> bf16,
 // K % 64 == 0, K >= 128.  DCC_ERR_UNSUPPORTED outside its domain.
 int dcc_gemm_p8_launch(const GemmParams& p, hipStream_t stream);

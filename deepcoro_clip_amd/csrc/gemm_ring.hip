@@ -743,11 +743,12 @@ int launch(const GemmParams& p, const Geo& geo, hipStream_t st) {
   constexpr int NS = 4;
   constexpr int LDS = NS * STAGE_B + CSTAGE_B;
   auto kern = gemm_ring_kernel<TC, A_KM, B_KM, NS>;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  const unsigned long long devbit = dcc_dev_bit();
+  if (!(configured & devbit)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return DCC_ERR_LAUNCH;
-    configured = true;
+    configured |= devbit;
   }
   int G = num_cus() & ~7;
   if (G < 8) G = 8;
@@ -788,16 +789,17 @@ int dcc_gemm_ring_launch(const GemmParams& p, int a_km, int b_km, int out_dtype,
   geo.items = (int)items;
   geo.ksteps = (p.K + BK - 1) / BK;
   geo.per = (geo.ksteps + p.splitk - 1) / p.splitk;
+  static const bool ring_v1 = getenv("DCC_RING_V1") != nullptr;   // A/B knob: read once
   if (out_dtype == DCC_BF16 && p.splitk == 1 && !(p.flags & (GEMM_ACCUM | GEMM_COLSUM_A)) && geo.ksteps >= 2 &&
-      !getenv("DCC_RING_V1")) {
+      !ring_v1) {
     constexpr int LDS2 = NS2 * STAGE_B + MB_B;
 #define RING2(AK, BK_)                                                                                              \
   do {                                                                                                              \
     auto kern = gemm_ring2_kernel<AK, BK_, false>;                                                                  \
-    static bool cfg = false;                                                                                        \
-    if (!cfg) {                                                                                                     \
+    static unsigned long long cfg = 0;                                                                              \
+    if (!(cfg & dcc_dev_bit())) {                                                                                   \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return DCC_ERR_LAUNCH; \
-      cfg = true;                                                                                                   \
+      cfg |= dcc_dev_bit();                                                                                         \
     }                                                                                                               \
     int G = num_cus() & ~7;                                                                                         \
     if (G < 8) G = 8;                                                                                               \
@@ -853,10 +855,10 @@ int dcc_gemm_ring_launch_fp8(const GemmParams& p, hipStream_t st) {
 #define F8_LAUNCH(FMT_)                                                                                                          \
   do {                                                                                                                           \
     auto kern = gemm_ring2_kernel<false, false, true, FMT_>;                                                                     \
-    static bool cfg = false;                                                                                                     \
-    if (!cfg) {                                                                                                                  \
+    static unsigned long long cfg = 0;                                                                                        \
+    if (!(cfg & dcc_dev_bit())) {                                                                                               \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return DCC_ERR_LAUNCH; \
-      cfg = true;                                                                                                                \
+      cfg |= dcc_dev_bit();                                                                                                      \
     }                                                                                                                            \
     hipLaunchKernelGGL(kern, dim3(G), dim3(NT2), LDS2, st, p, geo);                                                              \
   } while (0)

@@ -204,11 +204,12 @@ __global__ __launch_bounds__(SNT, MINW) void gemm_stream_kernel(GemmParams p, St
 template <int KK, int MINW, int EP>
 int stream_launch_ep(const GemmParams& p, const StreamGeo& geo, int lds, int chunks, hipStream_t st) {
   auto kern = gemm_stream_kernel<KK, MINW, EP>;
-  static int configured = 0;
-  if (configured < lds) {
+  static unsigned long long configured = 0;
+  const unsigned long long devbit = dcc_dev_bit();
+  if (!(configured & devbit)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return DCC_ERR_LAUNCH;
-    configured = 160 * 1024;
+    configured |= devbit;
   }
   // persistent waves: enough workgroups to fill every CU at the occupancy LDS and registers allow, never more than the work
   int per_cu = (160 * 1024) / (lds + 512);

@@ -291,11 +291,12 @@ int wide_launch(const GemmParams& p, const WGeo& geo, hipStream_t st) {
   constexpr int STRIP = 8 * (WBM / WM) * (2 * 64 + 16);
   constexpr int LDS = (WNS * STAGE > STRIP) ? WNS * STAGE : STRIP;
   auto kern = gemm_wide_kernel<TC, A_KM, B_KM, BN, NS>;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  const unsigned long long devbit = dcc_dev_bit();
+  if (!(configured & devbit)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return DCC_ERR_LAUNCH;
-    configured = true;
+    configured |= devbit;
   }
   const int G = (geo.items + 7) & ~7;
   hipLaunchKernelGGL(kern, dim3(G), dim3(WNT), LDS, st, p, geo);

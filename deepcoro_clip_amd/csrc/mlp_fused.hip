@@ -566,7 +566,12 @@ int mlp_launch(const MlpParams& p, hipStream_t st) {
   constexpr int LDS = 3 * mlp_stage_bytes<C>() + (4 * C + (Cfg::SR == 32 ? 3 * C : 0)) * 4 + Cfg::NW * Cfg::SR * MSTG_PITCH;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = ln_mlp_kernel<C, Cfg::NW, Cfg::HS, Cfg::MINW, Cfg::SR, Cfg::HAND>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DCC_ERR_LAUNCH;
+  static unsigned long long configured = 0;
+  const unsigned long long devbit = dcc_dev_bit();
+  if (!(configured & devbit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DCC_ERR_LAUNCH;
+    configured |= devbit;
+  }
   int per_cu = (160 * 1024) / LDS;
   if (per_cu > 1) per_cu = 1;   // one ring per CU: the workgroup's waves already fill the SIMDs to MINW
   int gx = 256 * per_cu;

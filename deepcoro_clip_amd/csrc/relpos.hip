@@ -841,12 +841,13 @@ static int relpos_bwd_launch(const void* dQf, const void* Qf, void* dq, const vo
   auto k2 = relpos_bwd_mfma_kernel<2, false>;
   auto k1l = relpos_bwd_mfma_kernel<1, true>;
   auto k2l = relpos_bwd_mfma_kernel<2, true>;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  const unsigned long long devbit = dcc_dev_bit();
+  if (!(configured & devbit)) {
     for (const void* f : {reinterpret_cast<const void*>(k1), reinterpret_cast<const void*>(k2), reinterpret_cast<const void*>(k1l),
                           reinterpret_cast<const void*>(k2l)})
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return DCC_ERR_LAUNCH;
-    configured = true;
+    configured |= devbit;
   }
   const RelLn ln = lnp ? *lnp : RelLn{nullptr, nullptr, nullptr, nullptr};
   auto kern = lnp ? (LPp <= 128 ? k1l : k2l) : (LPp <= 128 ? k1 : k2);
@@ -910,12 +911,13 @@ extern "C" int dcc_relpos_aug_fwd_mfma(void* Qf, const void* Rcat, const int* id
   const RelDiv dv{mkdiv(g.H), mkdiv(g.qt * g.qh * g.qw + g.has_cls), mkdiv(g.qw * g.qh), mkdiv(g.qw), mkdiv(1), mkdiv(1)};
   auto k1 = relpos_fwd_mfma_kernel<1>;
   auto k2 = relpos_fwd_mfma_kernel<2>;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  const unsigned long long devbit = dcc_dev_bit();
+  if (!(configured & devbit)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
       return DCC_ERR_LAUNCH;
-    configured = true;
+    configured |= devbit;
   }
   if (LPp <= 128) hipLaunchKernelGGL(k1, dim3((unsigned)nb), dim3(256), lds, st, (bf16_t*)Qf, (const bf16_t*)Rcat, idx_h, idx_w, idx_t, g, dv, 1.0f / scale, (unsigned)rows, LPp, ppitch, (unsigned)ntiles);
   else hipLaunchKernelGGL(k2, dim3((unsigned)nb), dim3(256), lds, st, (bf16_t*)Qf, (const bf16_t*)Rcat, idx_h, idx_w, idx_t, g, dv, 1.0f / scale, (unsigned)rows, LPp, ppitch, (unsigned)ntiles);

@@ -385,6 +385,67 @@ class Linear2Fn(torch.autograd.Function):
         return (dx, *grads)
 
 
+class LinearNSkipFn(torch.autograd.Function):
+    """N Linear layers of ONE input that also feeds a residual branch (BERT's post-LN layer: the LayerNorm output goes to
+    `self.query / key / value` and, unchanged, to the attention output's residual add — HF BertLayer via models/text_encoder.py:52).
+    Returns (y_1 .. y_N, x'): x' is an alias of x for the residual consumer, so that ALL gradients of x meet in this node and are
+    summed by the data-gradient GEMMs' residual epilogues (autograd otherwise launches N elementwise adds per layer)."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        Kd = x.shape[-1]
+        x2 = _c(x).reshape(-1, Kd)
+        ws, bs = wb[0::2], wb[1::2]
+        wcs = [wcast(w, x.dtype) for w in ws]
+        ys = [K.gemm(x2, wc, bias=b.detach() if b is not None else None) for wc, b in zip(wcs, bs)]
+        ctx.save_for_backward(x2, *wcs)
+        ctx.params = (ws, bs)
+        ctx.xshape = x.shape
+        return (*[y.reshape(*x.shape[:-1], w.shape[0]) for y, w in zip(ys, ws)], x.view_as(x))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x2, *wcs = ctx.saved_tensors
+        ws, bs = ctx.params
+        n = len(ws)
+        dskip = dys[n]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _as_dtype(_c(dskip).reshape(x2.shape), x2.dtype) if dskip is not None else None
+            for dy, w, wc in zip(dys[:n], ws, wcs):
+                if dy is None:
+                    continue
+                g = _c(dy).reshape(-1, wc.shape[0])
+                dx = _dx_gemm(g, w, wc, resid=dx) if dx is not None else _dx_gemm(g, w, wc)
+            dx = dx.reshape(ctx.xshape) if dx is not None else None
+        grads = []
+        for i, (dy, w, b) in enumerate(zip(dys[:n], ws, bs)):
+            dw = db = None
+            if dy is not None:
+                g = _c(dy).reshape(-1, w.shape[0])
+                want_db = b is not None and ctx.needs_input_grad[2 + 2 * i]
+                if ctx.needs_input_grad[1 + 2 * i]:
+                    if want_db:
+                        db = _grad_slots.take(b)
+                        if db is None:
+                            db = zeros_f32(g.shape[1], g.device)
+                    dw = wgrad(g, x2, db, side=WGRAD_SIDE and grads_unset(w, b), out=_grad_slots.take(w))
+                elif want_db:
+                    db = K.colsum(g)
+            grads += [dw, db]
+        return (dx, *grads)
+
+
+def linears_skip(x, *layers):
+    """layers: (weight, bias) pairs -> (y_1, ..., y_N, x') with x' the alias of x for its residual use.  fp8 GEMM mode and fp32
+    compute keep the plain nodes."""
+    M = x.numel() // x.shape[-1]
+    if any(_fp8_ok(M, x.shape[-1], w.shape[0], x.dtype) for w, _ in layers):
+        return (*[linear(x, w, b) for w, b in layers], x)
+    flat = [t for wb in layers for t in wb]
+    return LinearNSkipFn.apply(x, *flat)
+
+
 def linear2(x, w1, b1, w2, b2):
     """(linear(x, w1, b1), linear(x, w2, b2)) with one fused data gradient; fp8 GEMM mode keeps the two separate layers."""
     M = x.numel() // x.shape[-1]
@@ -400,6 +461,8 @@ class MlpFn(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2, residual):
         Kd = x.shape[-1]
         x2 = _c(x).reshape(-1, Kd)
+        # y = x + mlp(x) (BERT's post-LN feed-forward): the residual's gradient IS dy and joins dx in the last GEMM's epilogue
+        ctx.res_is_x = residual is x
         w1c, w2c = wcast(w1, x.dtype), wcast(w2, x.dtype)
         Hd, N = w1.shape[0], w2.shape[0]
         pre = torch.empty((x2.shape[0], Hd), device=x.device, dtype=x.dtype)
@@ -455,6 +518,9 @@ class MlpFn(torch.autograd.Function):
                 p8, sp = K.fp8_quantize(dpre, 1)
                 w1t8, s1t = wquant(ctx.params[0], True)
                 dx = K.gemm_fp8(p8, w1t8, sp, s1t, fmt_a=1).reshape(ctx.xshape)
+            elif ctx.res_is_x and dy2.dtype == x2.dtype:
+                dx = _dx_gemm(dpre, ctx.params[0], w1c, resid=dy2).reshape(ctx.xshape)
+                return dx, dw1, db1, dw2, db2, None
             else:
                 dx = _dx_gemm(dpre, ctx.params[0], w1c).reshape(ctx.xshape)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
@@ -683,7 +749,8 @@ FUSED_RELPOS = os.environ.get("DCC_FUSED_RELPOS", "1") != "0"
 # rel-pos backward as one MFMA kernel that builds dP per 64-row tile in LDS (dcc_relpos_aug_bwd) instead of scatter + two GEMMs
 FUSED_RELPOS_BWD = os.environ.get("DCC_FUSED_RELPOS_BWD", "1") != "0"
 # ... with the query pool's LayerNorm backward in its epilogue (dcc_relpos_aug_bwd_ln; without RoPE, whose inverse rotation sits
-# between the two); DCC_FUSED_RELPOS_LN=0 keeps rel-pos backward + layernorm_bwd as separate launches
+# between the two).  OFF by default — it wins isolated and loses in the step — DCC_FUSED_RELPOS_LN=1 enables
+# it; tests/test_relpos_fused_gpu.py exercises the kernel in the default GPU suite either way
 FUSED_RELPOS_LN = os.environ.get("DCC_FUSED_RELPOS_LN", "0") != "0"
 # depthwise-conv weight gradients of the q/k/v pools on the parameter-gradient side stream (joined at the end of backward)
 POOL_WGRAD_SIDE = os.environ.get("DCC_POOL_WGRAD_SIDE", "1") != "0"

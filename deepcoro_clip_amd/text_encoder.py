@@ -123,9 +123,9 @@ class HipBertModel(nn.Module):
         padrop = c.attention_probs_dropout_prob  # HF BertSelfAttention: dropout on the softmax output (training only)
         for l in self.encoder.layer:
             s = l.attention.self
-            q = Fn.linear(x, s.query.weight, s.query.bias).view(B, S, H, hd)
-            k = Fn.linear(x, s.key.weight, s.key.bias).view(B, S, H, hd)
-            v = Fn.linear(x, s.value.weight, s.value.bias).view(B, S, H, hd)
+            # one autograd node for the three projections + the residual use of x: their four gradients meet in GEMM epilogues
+            q, k, v, x = Fn.linears_skip(x, (s.query.weight, s.query.bias), (s.key.weight, s.key.bias), (s.value.weight, s.value.bias))
+            q, k, v = q.view(B, S, H, hd), k.view(B, S, H, hd), v.view(B, S, H, hd)
             ctx = Fn.attention(q, k, v, 1.0 / math.sqrt(hd), kbias, dropout_p=padrop, training=self.training).view(B * S, c.hidden_size)
             o = l.attention.output
             if self.training and pdrop > 0:

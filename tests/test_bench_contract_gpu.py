@@ -30,7 +30,9 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     rf = out["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and "traffic" in rf
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert rf["frac"] == max(rf["mfma"]["frac"], rf["hbm"]["frac"]) and 0 < rf["video_fwd_frac"] < 1
+    # bf16: the headline fraction is the MFMA one (SURVEY §8d classifies the GEMM family as MFMA-bound); the HBM view sits beside it
+    assert rf["bound"] == "mfma" and rf["frac"] == rf["mfma"]["frac"] and rf["binding_by_bytes_moved"] in ("hbm", "mfma")
+    assert "traffic_source" in rf and "instrumented" in rf["roofline_pass"] and 0 < rf["video_fwd_frac"] < 1
     cb = out["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"] and cb["unit"]
 
