@@ -87,7 +87,9 @@ def test_config4_encoder_fwd_bwd_n8_32f_rope_tokens(gemm_dtype):
     if gemm_dtype == "bf16":
         assert err < 5e-2 and cos.median() > 0.995 and cos.min() > 0.9, (err, cos.median().item(), worst)
     else:
-        assert err < 1.5e-1 and cos.median() > 0.97 and cos.min() > 0.5, (err, cos.median().item(), worst)
+        # measured (r03 / r04): tokens 1.3e-1 of the max, gradient cosine median 0.993, min 0.941: bars = 1.5 x the error, and a
+        # worst-tensor cosine that a sign error or a dropped term in ANY one tensor fails
+        assert err < 2.0e-1 and cos.median() > 0.98 and cos.min() > 0.9, (err, cos.median().item(), worst)
 
 
 def test_config4_train_step_fp8_rope_n8():

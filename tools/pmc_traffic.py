@@ -15,7 +15,7 @@ def family_totals(d, ctr):
             if r.get("Counter_Name") != ctr:
                 continue
             name = re.sub(r"\(anonymous namespace\)::|^void ", "", r["Kernel_Name"])
-            fam = "gemm" if "gemm_" in name else ("attn" if "attn_" in name else name.split("(")[0][:60])
+            fam = "gemm" if ("gemm_" in name or "ln_mlp_kernel" in name) else ("attn" if "attn_" in name else name.split("(")[0][:60])
             agg[fam][0] += 1
             agg[fam][1] += float(r["Counter_Value"])
     return agg
