@@ -16,6 +16,9 @@
 // rows, queries on lanes) or S (queries on rows, keys on lanes) so that the softmax statistics
 // are per-lane scalars and the probability tile feeds the next MFMA straight from the
 // accumulator registers (cdna guide: "accumulator tile as the next MFMA's operand").
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 
 struct AttnParams {
@@ -47,6 +50,16 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr int ANT = 256;  // threads per block
+// minimum waves per SIMD the register allocation must leave room for (hipcc otherwise spends up to 512 registers per lane)
+#ifndef DCC_ATTN_OCC_FWD
+#define DCC_ATTN_OCC_FWD 1
+#endif
+#ifndef DCC_ATTN_OCC_DQ
+#define DCC_ATTN_OCC_DQ 1
+#endif
+#ifndef DCC_ATTN_OCC_DKV
+#define DCC_ATTN_OCC_DKV 1
+#endif
 
 struct DropCtx {
   uint64_t seed; uint32_t thr; float inv_keep;
@@ -258,7 +271,7 @@ __device__ __forceinline__ Blk3 xcd_blk3() {
 // ------------------------------------------------------------------------------------------
 // forward: one wave = 32 queries, block = 128 queries; keys/values staged 64 rows at a time.
 template <typename T, int DQK, int DV, bool DROP>
-__global__ __launch_bounds__(ANT) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(ANT, DCC_ATTN_OCC_FWD) void attn_fwd_kernel(AttnParams p) {
   using KT = RowTile<T, DQK>;
   using VT = RowTile<T, DV>;
   __shared__ __attribute__((aligned(16))) char smem[TK * KT::PITCH + TK * VT::PITCH + TK * 4];
@@ -371,7 +384,7 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------
 // dQ: same decomposition as the forward (queries on lanes).
 template <typename T, int DQK, int DV, bool DROP>
-__global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(ANT, DCC_ATTN_OCC_DQ) void attn_bwd_dq_kernel(AttnParams p) {
   using KT = RowTile<T, DQK>;
   using VT = RowTile<T, DV>;
   __shared__ __attribute__((aligned(16))) char smem[TK * KT::PITCH + TK * VT::PITCH + TK * 4];
@@ -493,10 +506,13 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// dK/dV: keys on lanes (one wave = 32 keys, block = 128 keys), queries staged 64 rows at a time.
+// dK/dV: keys on lanes (one wave = KW tiles of 32 keys, block = 128 KW keys), queries staged 64 rows at a time.
 // blockIdx.x = key block * qsplit + query split.
-template <typename T, typename TO, int DQK, int DV, bool DROP>
-__global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
+// KW = 2: every Q / dO fragment read from LDS (row and transposed) feeds two MFMAs, which halves the LDS bytes per MFMA — with one
+// key tile per wave the kernel's LDS reads (14 b128 + 28 tr_b64 per 28 MFMAs) take as long as the MFMAs themselves.  The price is
+// the doubled accumulator / K,V fragment set: one wave per SIMD.
+template <typename T, typename TO, int DQK, int DV, bool DROP, int KW>
+__global__ __launch_bounds__(ANT, (KW > 1 ? 1 : DCC_ATTN_OCC_DKV)) void attn_bwd_dkv_kernel(AttnParams p) {
   using QT = RowTile<T, DQK>;
   using OT = RowTile<T, DV>;
   constexpr int TPITCH = DQK + 4;  // fp32 pitch of the per-wave transposition tile of the split epilogue
@@ -512,8 +528,7 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
   const Blk3 blk = xcd_blk3();
   const int b = blk.z, hd = blk.y;
   const int kblk = blk.x / p.qsplit, qs = blk.x % p.qsplit;
-  const int k0 = kblk * 128 + wave * 32;
-  const int mykey = k0 + (lane & 31);
+  const int k0 = kblk * (128 * KW) + wave * (32 * KW);   // tile kw of this wave starts at k0 + 32 kw
   const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.sqb + hd * p.sqh;
   const T* K = reinterpret_cast<const T*>(p.K) + b * p.skb + hd * p.skh;
   const T* V = reinterpret_cast<const T*>(p.V) + b * p.svb + hd * p.svh;
@@ -521,23 +536,27 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
   const float* LSE = p.LSE + ((int64_t)b * p.H + hd) * p.Nq;
   const float* Dv = p.Dv + ((int64_t)b * p.H + hd) * p.Nq;
 
-  frag_t<T> kf[DQK / 16], vf[DV / 16];
+  frag_t<T> kf[KW][DQK / 16], vf[KW][DV / 16];
+  float kb2[KW];
+  f32x16 dk[KW][DQK / 32], dvv[KW][DV / 32];
 #pragma unroll
-  for (int s = 0; s < DQK / 16; ++s) kf[s] = gfrag<T>(K, p.skn, mykey, p.Nk, s, h);
+  for (int kw = 0; kw < KW; ++kw) {
+    const int mykey = k0 + 32 * kw + (lane & 31);
 #pragma unroll
-  for (int s = 0; s < DV / 16; ++s) vf[s] = gfrag<T>(V, p.svn, mykey, p.Nk, s, h);
-  float kb2 = -INFINITY;
-  if (mykey < p.Nk) kb2 = p.kbias ? p.kbias[(int64_t)b * p.Nk + mykey] * LOG2E : 0.0f;
-
-  f32x16 dk[DQK / 32], dvv[DV / 32];
+    for (int s = 0; s < DQK / 16; ++s) kf[kw][s] = gfrag<T>(K, p.skn, mykey, p.Nk, s, h);
 #pragma unroll
-  for (int t = 0; t < DQK / 32; ++t)
+    for (int s = 0; s < DV / 16; ++s) vf[kw][s] = gfrag<T>(V, p.svn, mykey, p.Nk, s, h);
+    kb2[kw] = -INFINITY;
+    if (mykey < p.Nk) kb2[kw] = p.kbias ? p.kbias[(int64_t)b * p.Nk + mykey] * LOG2E : 0.0f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dk[t][e] = 0.0f;
+    for (int t = 0; t < DQK / 32; ++t)
 #pragma unroll
-  for (int t = 0; t < DV / 32; ++t)
+      for (int e = 0; e < 16; ++e) dk[kw][t][e] = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dvv[t][e] = 0.0f;
+    for (int t = 0; t < DV / 32; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dvv[kw][t][e] = 0.0f;
+  }
   const float scale2 = p.scale * LOG2E;
 
   DropCtx dc;
@@ -575,39 +594,491 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
     for (int sub = 0; sub < TK / 32; ++sub) {
       if (qq0 + 32 * sub >= p.Nq || k0 >= p.Nk) break;  // no queries left / this wave owns no valid key
-      f32x16 S, dP;
+      f32x16 S[KW], dP[KW];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { S[e] = 0.0f; dP[e] = 0.0f; }
+      for (int kw = 0; kw < KW; ++kw)
 #pragma unroll
-      for (int s = 0; s < DQK / 16; ++s) S = mma16(row_frag<T, DQK>(ldsQ, 32 * sub, s, lane), kf[s], S);
+        for (int e = 0; e < 16; ++e) { S[kw][e] = 0.0f; dP[kw][e] = 0.0f; }
+      const bool two = KW > 1 && (k0 + 32 < p.Nk);  // the second key tile holds valid keys (wave-uniform)
 #pragma unroll
-      for (int s = 0; s < DV / 16; ++s) dP = mma16(row_frag<T, DV>(ldsO, 32 * sub, s, lane), vf[s], dP);
+      for (int s = 0; s < DQK / 16; ++s) {
+        const frag_t<T> a = row_frag<T, DQK>(ldsQ, 32 * sub, s, lane);
+        S[0] = mma16(a, kf[0][s], S[0]);
+        if constexpr (KW > 1) { if (two) S[KW - 1] = mma16(a, kf[KW - 1][s], S[KW - 1]); }
+      }
+#pragma unroll
+      for (int s = 0; s < DV / 16; ++s) {
+        const frag_t<T> a = row_frag<T, DV>(ldsO, 32 * sub, s, lane);
+        dP[0] = mma16(a, vf[0][s], dP[0]);
+        if constexpr (KW > 1) { if (two) dP[KW - 1] = mma16(a, vf[KW - 1][s], dP[KW - 1]); }
+      }
       // rows = queries, lanes = keys
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int qi = 32 * sub + acc_row(e, h);
-        const float pr = fast_exp2(S[e] * scale2 + kb2 - ldsL[qi]);
-        if constexpr (DROP) {
-          const float mk = dc.mul(drow0 + (uint32_t)(qq0 + qi), (uint32_t)mykey);
-          S[e] = pr * mk;                        // dropout(P): feeds dV
-          dP[e] = pr * (dP[e] * mk - ldsD[qi]);  // dz
-        } else {
-          S[e] = pr;                        // P
-          dP[e] = pr * (dP[e] - ldsD[qi]);  // dz
+        const float lq = ldsL[qi], dq_ = ldsD[qi];
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          const float pr = fast_exp2(S[kw][e] * scale2 + kb2[kw] - lq);
+          if constexpr (DROP) {
+            const float mk = dc.mul(drow0 + (uint32_t)(qq0 + qi), (uint32_t)(k0 + 32 * kw + (lane & 31)));
+            S[kw][e] = pr * mk;                          // dropout(P): feeds dV
+            dP[kw][e] = pr * (dP[kw][e] * mk - dq_);    // dz
+          } else {
+            S[kw][e] = pr;                           // P
+            dP[kw][e] = pr * (dP[kw][e] - dq_);      // dz
+          }
         }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const frag_t<T> pf = acc_as_frag<T>(S, s2);
-        const frag_t<T> zf = acc_as_frag<T>(dP, s2);
+        frag_t<T> pf[KW], zf[KW];
 #pragma unroll
-        for (int t = 0; t < DV / 32; ++t)
-          dvv[t] = mma16(tr_frag<T, DV>(ldsO, 32 * sub, s2, 32 * t, lane), pf, dvv[t]);
+        for (int kw = 0; kw < KW; ++kw) { pf[kw] = acc_as_frag<T>(S[kw], s2); zf[kw] = acc_as_frag<T>(dP[kw], s2); }
 #pragma unroll
-        for (int t = 0; t < DQK / 32; ++t)
-          dk[t] = mma16(tr_frag<T, DQK>(ldsQ, 32 * sub, s2, 32 * t, lane), zf, dk[t]);
+        for (int t = 0; t < DV / 32; ++t) {
+          const frag_t<T> a = tr_frag<T, DV>(ldsO, 32 * sub, s2, 32 * t, lane);
+          dvv[0][t] = mma16(a, pf[0], dvv[0][t]);
+          if constexpr (KW > 1) { if (two) dvv[KW - 1][t] = mma16(a, pf[KW - 1], dvv[KW - 1][t]); }
+        }
+#pragma unroll
+        for (int t = 0; t < DQK / 32; ++t) {
+          const frag_t<T> a = tr_frag<T, DQK>(ldsQ, 32 * sub, s2, 32 * t, lane);
+          dk[0][t] = mma16(a, zf[0], dk[0][t]);
+          if constexpr (KW > 1) { if (two) dk[KW - 1][t] = mma16(a, zf[KW - 1], dk[KW - 1][t]); }
+        }
       }
     }
+  }
+
+  if (p.qsplit == 1) {
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw) {
+      const int mykey = k0 + 32 * kw + (lane & 31);
+      if (mykey < p.Nk) {
+        TO* dkrow = reinterpret_cast<TO*>(p.dK) + b * p.sdkb + hd * p.sdkh + (int64_t)mykey * p.sdkn;
+        TO* dvrow = reinterpret_cast<TO*>(p.dV) + b * p.sdvb + hd * p.sdvh + (int64_t)mykey * p.sdvn;
+#pragma unroll
+        for (int t = 0; t < DQK / 32; ++t) store_tile_T<TO, (DQK <= 128)>(dkrow, t, h, dk[kw][t], p.scale, nullptr);
+#pragma unroll
+        for (int t = 0; t < DV / 32; ++t) store_tile_T<TO, (DQK <= 128)>(dvrow, t, h, dvv[kw][t], 1.0f, nullptr);
+      }
+    }
+  } else if constexpr (sizeof(TO) == 4) {
+    // query-split partial sums: transpose each wave's [32 keys][D] tile through LDS so that one atomic
+    // wave-instruction covers 256 contiguous bytes of ONE row (row-per-lane atomics run ~17x slower)
+    __syncthreads();  // all waves are done with the staged Q / dO tiles
+    float* tw = reinterpret_cast<float*>(smem) + wave * (32 * TPITCH);
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw) {
+      const int kk0 = k0 + 32 * kw;
+      // dK
+#pragma unroll
+      for (int t = 0; t < DQK / 32; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tw[(lane & 31) * TPITCH + 32 * t + acc_row(e, h)] = dk[kw][t][e] * p.scale;
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+      for (int r = 0; r < 32; ++r) {
+        const int key = kk0 + r;
+        if (key >= p.Nk) break;
+        float* dst = reinterpret_cast<float*>(p.dK) + b * p.sdkb + hd * p.sdkh + (int64_t)key * p.sdkn;
+        for (int c = lane; c < DQK; c += 64) atomicAdd(dst + c, tw[r * TPITCH + c]);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      // dV
+#pragma unroll
+      for (int t = 0; t < DV / 32; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tw[(lane & 31) * TPITCH + 32 * t + acc_row(e, h)] = dvv[kw][t][e];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      for (int r = 0; r < 32; ++r) {
+        const int key = kk0 + r;
+        if (key >= p.Nk) break;
+        float* dst = reinterpret_cast<float*>(p.dV) + b * p.sdvb + hd * p.sdvh + (int64_t)key * p.sdvn;
+        for (int c = lane; c < DV; c += 64) atomicAdd(dst + c, tw[r * TPITCH + c]);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dK/dV, software-pipelined (bf16, no dropout).  Same decomposition as attn_bwd_dkv_kernel — one wave = 32 keys, K / V fragments and
+// the dK / dV accumulators in registers — but a lone wave per SIMD no longer runs its three phases back to back:
+//   A(j)  S = Q_j K^T, dP = dO_j V^T          MFMA, row fragments from LDS
+//   B(j)  P = exp2(..), dz = P (dP - D)        VALU
+//   C(j)  dV += P^T dO_j, dK += dz^T Q_j       MFMA, transposed fragments from LDS
+// Iteration j issues C(j-1), B(j) and A(j+1): the MFMAs of two neighbouring query tiles are independent of the softmax arithmetic
+// of the one between them, so the matrix pipe works while the VALU does exponentials.  Query tiles are 32 rows, four LDS buffers
+// (tiles j-1, j, j+1 live, j+2 being written): one barrier per tile.
+// scheduling groups (llvm.amdgcn.sched.group.barrier masks: 0x008 MFMA, 0x100 LDS read, 0x002 VALU)
+template <int N> __device__ __forceinline__ void sched_prime() {
+  if constexpr (N > 0) { __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); sched_prime<N - 1>(); }
+}
+template <int N, int NDS, int NVALU> __device__ __forceinline__ void sched_slots() {
+  if constexpr (N > 0) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);
+    sched_slots<N - 1, NDS, NVALU>();
+  }
+}
+#ifndef DCC_PIPE_DBG
+#define DCC_PIPE_DBG 0
+#endif
+#ifndef PIPE_VALU_C
+#define PIPE_VALU_C 5
+#endif
+#ifndef PIPE_VALU_A
+#define PIPE_VALU_A 3
+#endif
+#ifdef DCC_ATTN_PIPE_NOPS
+#define PIPE_NOPS "\n\ts_nop 15\n\ts_nop 3"
+#else
+#define PIPE_NOPS ""
+#endif
+// the same with the result retired when the statement ends: for the compiler-scheduled prologue / epilogue code, where the register
+// allocator may copy an accumulator tuple right behind the MFMA (it does not know the statement's latency)
+__device__ __forceinline__ void mma16_acc_retired(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mma16_vacc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" PIPE_NOPS : "+v"(acc) : "v"(a), "v"(b));
+}
+// NB: __builtin_bit_cast applied directly to a vector ELEMENT (v[i]) reads element 0 whatever i is (hipcc 7.2): go through a scalar
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+// first MFMA of a chain: C = 0 as an inline constant.  (Zeroing the accumulator with vector moves and accumulating into it needs wait
+// states between the last move and the MFMA that the compiler cannot know to insert for an inline-asm MFMA: the MFMA then reads the
+// registers' previous contents.)
+__device__ __forceinline__ void mma16_vinit(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" PIPE_NOPS : "=&v"(acc) : "v"(a), "v"(b));
+}
+// ---- hand-placed pieces of the pipelined kernel's steady state (the compiler neither counts nor waits for these LDS reads)
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+template <int OFF> __device__ __forceinline__ u32x4 hlds_b128(uint32_t addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ u32x2 hlds_tr64(uint32_t addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// wait until at most N younger LDS operations are outstanding; the fragment is an operand so that its consumer stays behind the wait
+template <int N> __device__ __forceinline__ void hwait(u32x4& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
+// dK / dV accumulate in AGPRs: the kernel is built with MFMA results in VGPRs (the softmax reads S and dP), and 112 more VGPRs
+// of accumulators would leave no room for the second S / dP pair and the fragments in flight
+__device__ __forceinline__ void mma16_acc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" PIPE_NOPS : "+a"(acc) : "v"(a), "v"(b));
+}
+
+constexpr int PT = 32;     // query rows per pipelined tile
+constexpr int PNBUF = 4;
+
+template <int DQK, int DV>
+struct PipeGeo {
+  using QT = RowTile<bf16_t, DQK>;
+  using OT = RowTile<bf16_t, DV>;
+  static constexpr int Q_BYTES = PT * QT::PITCH, O_BYTES = PT * OT::PITCH;
+  static constexpr int TILE_BYTES = Q_BYTES + O_BYTES + 2 * PT * 4;
+  static constexpr int TPITCH = DQK + 4;
+  static constexpr int TRANS_BYTES = 4 * 32 * TPITCH * 4;
+  static constexpr int LDS_BYTES = PNBUF * TILE_BYTES > TRANS_BYTES ? PNBUF * TILE_BYTES : TRANS_BYTES;
+  static constexpr int NQ = PT * QT::CPR, NO = PT * OT::CPR;            // 16-byte chunks per tile
+  static constexpr int RQ = (NQ + ANT - 1) / ANT, RO = (NO + ANT - 1) / ANT;  // chunks per thread
+};
+
+template <typename TO, int DQK, int DV>
+__global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
+  using T = bf16_t;
+  using G = PipeGeo<DQK, DV>;
+  using QT = typename G::QT;
+  using OT = typename G::OT;
+  extern __shared__ __attribute__((aligned(16))) char psmem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const Blk3 blk = xcd_blk3();
+  const int b = blk.z, hd = blk.y;
+  const int kblk = blk.x / p.qsplit, qs = blk.x % p.qsplit;
+  const int k0 = kblk * 128 + wave * 32;
+  const int mykey = k0 + (lane & 31);
+  const bool active = k0 < p.Nk;  // wave-uniform: this wave owns at least one valid key
+  const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.sqb + hd * p.sqh;
+  const T* K = reinterpret_cast<const T*>(p.K) + b * p.skb + hd * p.skh;
+  const T* V = reinterpret_cast<const T*>(p.V) + b * p.svb + hd * p.svh;
+  const T* dO = reinterpret_cast<const T*>(p.dO) + b * p.sob + hd * p.soh;
+  const float* LSE = p.LSE + ((int64_t)b * p.H + hd) * p.Nq;
+  const float* Dv = p.Dv + ((int64_t)b * p.H + hd) * p.Nq;
+
+  frag_t<T> kf[DQK / 16], vf[DV / 16];
+#pragma unroll
+  for (int s = 0; s < DQK / 16; ++s) kf[s] = gfrag<T>(K, p.skn, mykey, p.Nk, s, h);
+#pragma unroll
+  for (int s = 0; s < DV / 16; ++s) vf[s] = gfrag<T>(V, p.svn, mykey, p.Nk, s, h);
+  float kb2 = -INFINITY;
+  if (mykey < p.Nk) kb2 = p.kbias ? p.kbias[(int64_t)b * p.Nk + mykey] * LOG2E : 0.0f;
+
+  f32x16 dk[DQK / 32], dvv[DV / 32];
+#pragma unroll
+  for (int t = 0; t < DQK / 32; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dk[t][e] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < DV / 32; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dvv[t][e] = 0.0f;
+  const float scale2 = p.scale * LOG2E;
+
+  // query range of this split, in units of PT rows
+  const int qtiles = (p.Nq + PT - 1) / PT;
+  const int per = (qtiles + p.qsplit - 1) / p.qsplit;
+  const int qt_begin = qs * per;
+  int qt_end = qt_begin + per; if (qt_end > qtiles) qt_end = qtiles;
+  const int n = qt_end - qt_begin;  // tiles of this block (may be <= 0)
+
+  const __amdgpu_buffer_rsrc_t rsQ = tile_rsrc<T, DQK>(Q, p.sqn, p.Nq), rsO = tile_rsrc<T, DV>(dO, p.son, p.Nq);
+  const int qstride = (int)p.sqn * 2, ostride = (int)p.son * 2;
+  vec16_t<T> rq[G::RQ], ro[G::RO];
+  float rl = 0.0f;
+  auto gload = [&](int j) {  // global -> registers, tile j of this block
+    const int row0 = (qt_begin + j) * PT;
+#pragma unroll
+    for (int i = 0; i < G::RQ; ++i) {
+      const int id = tid + ANT * i;
+      if (G::NQ % ANT == 0 || id < G::NQ) {
+        const int rr = id / QT::CPR, c = id % QT::CPR;
+        rq[i] = __builtin_bit_cast(vec16_t<T>, __builtin_amdgcn_raw_buffer_load_b128(rsQ, (row0 + rr) * qstride + c * 16, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G::RO; ++i) {
+      const int id = tid + ANT * i;
+      if (G::NO % ANT == 0 || id < G::NO) {
+        const int rr = id / OT::CPR, c = id % OT::CPR;
+        ro[i] = __builtin_bit_cast(vec16_t<T>, __builtin_amdgcn_raw_buffer_load_b128(rsO, (row0 + rr) * ostride + c * 16, 0, 0));
+      }
+    }
+    if (tid < 2 * PT) {  // lanes 0..31: LSE (log2 units), lanes 32..63: D
+      const int q = row0 + (tid & (PT - 1));
+      if (tid < PT) rl = (q < p.Nq) ? LSE[q] * LOG2E : INFINITY;
+      else rl = (q < p.Nq) ? Dv[q] : 0.0f;
+    }
+  };
+  auto lstore = [&](int j) {  // registers -> LDS buffer of tile j
+    char* base = psmem + (j & (PNBUF - 1)) * G::TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < G::RQ; ++i) {
+      const int id = tid + ANT * i;
+      if (G::NQ % ANT == 0 || id < G::NQ) {
+        const int rr = id / QT::CPR, c = id % QT::CPR;
+        *reinterpret_cast<vec16_t<T>*>(base + rr * QT::PITCH + c * 16) = rq[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G::RO; ++i) {
+      const int id = tid + ANT * i;
+      if (G::NO % ANT == 0 || id < G::NO) {
+        const int rr = id / OT::CPR, c = id % OT::CPR;
+        *reinterpret_cast<vec16_t<T>*>(base + G::Q_BYTES + rr * OT::PITCH + c * 16) = ro[i];
+      }
+    }
+    if (tid < 2 * PT) reinterpret_cast<float*>(base + G::Q_BYTES + G::O_BYTES)[tid] = rl;
+  };
+  auto phaseA = [&](int j, f32x16& S, f32x16& dP) {
+    const char* base = psmem + (j & (PNBUF - 1)) * G::TILE_BYTES;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { S[e] = 0.0f; dP[e] = 0.0f; }
+#pragma unroll
+    for (int s = 0; s < DQK / 16; ++s) S = mma16(row_frag<T, DQK>(base, 0, s, lane), kf[s], S);
+#pragma unroll
+    for (int s = 0; s < DV / 16; ++s) dP = mma16(row_frag<T, DV>(base + G::Q_BYTES, 0, s, lane), vf[s], dP);
+  };
+  auto phaseB = [&](int j, const f32x16& S, const f32x16& dP, frag_t<T>* pf, frag_t<T>* zf) {
+    const float* ld = reinterpret_cast<const float*>(psmem + (j & (PNBUF - 1)) * G::TILE_BYTES + G::Q_BYTES + G::O_BYTES);
+    f32x16 P, Z;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(ld + 8 * g + 4 * h);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(ld + PT + 8 * g + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = 4 * g + i;
+        const float pr = fast_exp2(S[e] * scale2 + kb2 - l4[i]);
+        P[e] = pr;
+        Z[e] = pr * (dP[e] - d4[i]);
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) { pf[s2] = acc_as_frag<T>(P, s2); zf[s2] = acc_as_frag<T>(Z, s2); }
+  };
+  auto phaseC = [&](int j, const frag_t<T>* pf, const frag_t<T>* zf) {
+    const char* base = psmem + (j & (PNBUF - 1)) * G::TILE_BYTES;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int t = 0; t < DV / 32; ++t) mma16_acc_retired(dvv[t], tr_frag<T, DV>(base + G::Q_BYTES, 0, s2, 32 * t, lane), pf[s2]);
+#pragma unroll
+      for (int t = 0; t < DQK / 32; ++t) mma16_acc_retired(dk[t], tr_frag<T, DQK>(base, 0, s2, 32 * t, lane), zf[s2]);
+    }
+  };
+
+  // steady-state iteration j, by hand: C(j-1) with (pf, zf), B(j) on (S, dP) -> (pfn, zfn), A(j+1) -> (Sn, dPn)
+  auto steady = [&](int j, f32x16& S, f32x16& dP, f32x16& Sn, f32x16& dPn, frag_t<T>* pf, frag_t<T>* zf, frag_t<T>* pfn, frag_t<T>* zfn) {
+#ifdef DCC_ATTN_PIPE_PLAIN   // the same dataflow, compiler-scheduled (debugging aid)
+    phaseC(j - 1, pf, zf);
+    phaseB(j, S, dP, pfn, zfn);
+    phaseA(j + 1, Sn, dPn);
+    return;
+#endif
+        // NC + NA slots, one MFMA each: slot k issues the LDS reads of the fragment of slot k + AHEAD, waits for its own, then runs
+        // its MFMA and its share of B(j)
+        constexpr int NCH = DV / 32 + DQK / 32, NC = 2 * NCH, NA = DQK / 16 + DV / 16, NS = NC + NA, AHEAD = 3;
+        const uint32_t lbase = (uint32_t)(uintptr_t)LDS_PTR(const char, psmem);
+        const uint32_t bC = lbase + ((j - 1) & (PNBUF - 1)) * G::TILE_BYTES, bA = lbase + ((j + 1) & (PNBUF - 1)) * G::TILE_BYTES;
+        const uint32_t bB = lbase + (j & (PNBUF - 1)) * G::TILE_BYTES + G::Q_BYTES + G::O_BYTES;
+        const int i16 = lane & 15, tq = i16 >> 2, tpp = i16 & 3, tg = (lane >> 4) & 1;
+        const uint32_t trQ = bC + (4 * h + tq) * QT::PITCH + (16 * tg + 4 * tpp) * 2;
+        const uint32_t trO = bC + G::Q_BYTES + (4 * h + tq) * OT::PITCH + (16 * tg + 4 * tpp) * 2;
+        const uint32_t rwQ = bA + (lane & 31) * QT::PITCH + 16 * h;
+        const uint32_t rwO = bA + G::Q_BYTES + (lane & 31) * OT::PITCH + 16 * h;
+        const uint32_t ldL = bB + 16 * h;
+        u32x4 fr[AHEAD + 1];
+        u32x4 l4[4], d4[4];
+        auto issue = [&](auto kc) {   // LDS reads of slot k's fragment
+          constexpr int k = decltype(kc)::value;
+          if constexpr (k < NC) {
+            constexpr int s2 = k / NCH, r = k % NCH;
+            if constexpr (r < DV / 32) {
+              const u32x2 lo = hlds_tr64<(16 * s2) * OT::PITCH + 64 * r>(trO), hi = hlds_tr64<(16 * s2 + 8) * OT::PITCH + 64 * r>(trO);
+              fr[k % (AHEAD + 1)] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            } else {
+              constexpr int t = r - DV / 32;
+              const u32x2 lo = hlds_tr64<(16 * s2) * QT::PITCH + 64 * t>(trQ), hi = hlds_tr64<(16 * s2 + 8) * QT::PITCH + 64 * t>(trQ);
+              fr[k % (AHEAD + 1)] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+          } else if constexpr (k < NS) {
+            constexpr int a = k - NC;
+            if constexpr (a < DQK / 16) fr[k % (AHEAD + 1)] = hlds_b128<32 * a>(rwQ);
+            else fr[k % (AHEAD + 1)] = hlds_b128<32 * (a - DQK / 16)>(rwO);
+          }
+        };
+        // LDS operations issued for slot k's fragment (what a wait on an older fragment must leave outstanding)
+        auto nops = [](int k) constexpr { return k < NC ? 2 : (k < NS ? 1 : 0); };
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<4>([&](auto gc) { constexpr int g = decltype(gc)::value; l4[g] = hlds_b128<32 * g>(ldL); d4[g] = hlds_b128<PT * 4 + 32 * g>(ldL); });
+        static_for<AHEAD>([&](auto kc) { issue(kc); });
+        static_for<NS>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          // wait first, then issue: at most 8 (L / D) + 2 * AHEAD operations are ever outstanding, within the 4-bit counter
+          hwait<nops(k + 1) + nops(k + 2)>(fr[k % (AHEAD + 1)]);
+          issue(std::integral_constant<int, k + AHEAD>{});
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 a = __builtin_bit_cast(bf16x8, fr[k % (AHEAD + 1)]);
+          if constexpr (k < NC) {
+            constexpr int s2 = k / NCH, r = k % NCH;
+            if constexpr (r < DV / 32) mma16_acc(dvv[r], a, pf[s2]);
+            else mma16_acc(dk[r - DV / 32], a, zf[s2]);
+          } else {
+            constexpr int q = k - NC;
+            // by hand as well (a compiler-placed MFMA whose result is needed an iteration later sinks to the end of the block); the
+            // vector reads of Sn / dPn are an iteration's worth of instructions away, far beyond the MFMA's result latency
+            if constexpr (q == 0) mma16_vinit(Sn, a, kf[0]);
+            else if constexpr (q < DQK / 16) mma16_vacc(Sn, a, kf[q]);
+            else if constexpr (q == DQK / 16) mma16_vinit(dPn, a, vf[0]);
+            else mma16_vacc(dPn, a, vf[q - DQK / 16]);
+          }
+          // B(j): P in slots 0..15, dz pairs in slots 16..23, the bf16 fragments of P in 16..23 and of dz in 24..27
+          constexpr bool VAL = DCC_PIPE_DBG != 1;
+          if constexpr (!VAL) {
+          } else if constexpr (k < 16) {
+            if constexpr (k == 0) {   // the L / D reads are older than every fragment read: they have landed with fragment 0
+#pragma unroll
+              for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(l4[g]), "+v"(d4[g]));
+            }
+            S[k] = fast_exp2(S[k] * scale2 + kb2 - u2f(l4[k >> 2][k & 3]));
+            asm volatile("" : "+v"(S[k]));
+          } else if constexpr (k < 24) {
+            constexpr int e = 2 * (k - 16);
+            dP[e] = S[e] * (dP[e] - u2f(d4[e >> 2][e & 3]));
+            dP[e + 1] = S[e + 1] * (dP[e + 1] - u2f(d4[(e + 1) >> 2][(e + 1) & 3]));
+            bf16x2 c; c[0] = (bf16_t)S[e]; c[1] = (bf16_t)S[e + 1];
+            pfn[e >> 3][e & 7] = c[0]; pfn[e >> 3][(e & 7) + 1] = c[1];
+            asm volatile("" : "+v"(dP[e]), "+v"(dP[e + 1]));
+          } else if constexpr (k < 28) {
+            constexpr int e0 = 4 * (k - 24);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zfn[(e0 + i) >> 3][(e0 + i) & 7] = (bf16_t)dP[e0 + i];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+#if DCC_PIPE_DBG == 1
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        phaseB(j, S, dP, pfn, zfn);
+#endif
+        static_assert(NS >= 28, "B(j) is spread over 28 slots");
+  };
+
+  if (n > 0) {
+    // prologue: tiles 0 and 1 into LDS, A(0); global loads run a whole iteration ahead of their LDS writes
+    gload(0);
+    lstore(0);
+    if (n > 1) { gload(1); lstore(1); }
+    if (n > 2) gload(2);
+    __syncthreads();
+    f32x16 S, dP, Sn, dPn;
+    frag_t<T> pf[2], zf[2], pfn[2], zfn[2];
+    // the tail of every iteration: tile j + 2 (loaded during the previous iteration) into LDS, loads of tile j + 3, barrier
+    auto tail = [&](int j) {
+#ifndef DCC_PIPE_EXP_NOLOAD   // (timing experiment: tiles are not refreshed)
+      if (j + 2 < n) lstore(j + 2);
+      if (j + 3 < n) gload(j + 3);
+#endif
+      __syncthreads();
+    };
+    // j = 0: B(0), A(1)
+    if (active) {
+      phaseA(0, S, dP);
+      phaseB(0, S, dP, pf, zf);
+      if (n > 1) phaseA(1, S, dP);
+    }
+    tail(0);
+    int j = 1;
+    if (j + 1 < n && ((n - 2) & 1)) {  // odd number of steady iterations: the first one compiler-scheduled, the rest in pairs
+      if (active) {
+        phaseC(0, pf, zf);
+        phaseB(1, S, dP, pf, zf);
+        phaseA(2, S, dP);
+      }
+      tail(1);
+      j = 2;
+    }
+    // pairs: the second iteration of a pair runs with the roles of (S, dP, pf, zf) and (Sn, dPn, pfn, zfn) swapped, so nothing is copied
+    for (; j + 1 < n; j += 2) {
+      if (active) steady(j, S, dP, Sn, dPn, pf, zf, pfn, zfn);
+      tail(j);
+      if (active) steady(j + 1, Sn, dPn, S, dP, pfn, zfn, pf, zf);
+      tail(j + 1);
+    }
+    // the hand-placed MFMAs' results are invisible to the compiler's hazard tracking: let the last ones retire before vector code reads them
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (active) {
+      if (n > 1) {  // j = n - 1: C(n-2), B(n-1)
+        phaseC(n - 2, pf, zf);
+        phaseB(n - 1, S, dP, pf, zf);
+      }
+      phaseC(n - 1, pf, zf);
+    }
+    // dK / dV come out of hand-written MFMAs: their last results must have retired before the stores below read the accumulators
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   if (p.qsplit == 1) {
@@ -620,16 +1091,14 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
       for (int t = 0; t < DV / 32; ++t) store_tile_T<TO, (DQK <= 128)>(dvrow, t, h, dvv[t], 1.0f, nullptr);
     }
   } else if constexpr (sizeof(TO) == 4) {
-    // query-split partial sums: transpose each wave's [32 keys][D] tile through LDS so that one atomic
-    // wave-instruction covers 256 contiguous bytes of ONE row (row-per-lane atomics run ~17x slower)
-    __syncthreads();  // all waves are done with the staged Q / dO tiles
-    float* tw = reinterpret_cast<float*>(smem) + wave * (32 * TPITCH);
-    // dK
+    constexpr int TPITCH = G::TPITCH;
+    __syncthreads();  // all waves are done with the staged tiles
+    float* tw = reinterpret_cast<float*>(psmem) + wave * (32 * TPITCH);
 #pragma unroll
     for (int t = 0; t < DQK / 32; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) tw[(lane & 31) * TPITCH + 32 * t + acc_row(e, h)] = dk[t][e] * p.scale;
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_s_waitcnt(0xc07f);
     for (int r = 0; r < 32; ++r) {
       const int key = k0 + r;
       if (key >= p.Nk) break;
@@ -637,7 +1106,6 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
       for (int c = lane; c < DQK; c += 64) atomicAdd(dst + c, tw[r * TPITCH + c]);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    // dV
 #pragma unroll
     for (int t = 0; t < DV / 32; ++t)
 #pragma unroll
@@ -652,6 +1120,36 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
+// DCC_ATTN_PIPE = 1 selects the pipelined dK/dV kernel (A/B runs; off by default until it is the faster one)
+inline bool attn_pipe_enabled() {
+  static const bool on = [] { const char* e = getenv("DCC_ATTN_PIPE"); return e && atoi(e) != 0; }();
+  return on;
+}
+
+template <typename TO, int DQK, int DV>
+int launch_dkv_pipe(const AttnParams& p, hipStream_t st) {
+  using G = PipeGeo<DQK, DV>;
+  static unsigned long long configured = 0;
+  const unsigned long long bit = dcc_dev_bit();
+  if (!(configured & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_pipe_kernel<TO, DQK, DV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            G::LDS_BYTES) != hipSuccess)
+      return DCC_ERR_LAUNCH;
+    configured |= bit;
+  }
+  dim3 grid(((p.Nk + 127) / 128) * p.qsplit, p.H, p.B);
+  hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<TO, DQK, DV>), grid, dim3(ANT), G::LDS_BYTES, st, p);
+  return dcc_check_launch();
+}
+
+// key tiles per wave of the dK/dV kernel: DCC_ATTN_KW = 1 | 2 forces it (A/B runs), default by shape
+inline int attn_kw(const AttnParams& p, int dqk) {
+  static const int forced = [] { const char* e = getenv("DCC_ATTN_KW"); return e ? atoi(e) : 0; }();
+  if (forced == 1 || forced == 2) return forced;
+  (void)p; (void)dqk;
+  return 1;
+}
+
 template <typename T, int DQK, int DV, bool DROP>
 int launch_attn(int which, const AttnParams& p, int out_f32, hipStream_t st) {
   if (which == 0) {
@@ -661,9 +1159,22 @@ int launch_attn(int which, const AttnParams& p, int out_f32, hipStream_t st) {
     dim3 grid((p.Nq + 127) / 128, p.H, p.B);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DQK, DV, DROP>), grid, dim3(ANT), 0, st, p);
   } else {
+    if constexpr (sizeof(T) == 2 && !DROP && DV == 96 && (DQK == 128 || DQK == 160)) {
+      if (attn_pipe_enabled()) return out_f32 ? launch_dkv_pipe<float, DQK, DV>(p, st) : launch_dkv_pipe<bf16_t, DQK, DV>(p, st);
+    }
+#ifdef DCC_ATTN_KW2   // needs AGPR accumulators: build attention.hip without -amdgpu-mfma-vgpr-form
+    if constexpr (sizeof(T) == 2 && !DROP) {
+      if (attn_kw(p, DQK) == 2) {
+        dim3 grid(((p.Nk + 255) / 256) * p.qsplit, p.H, p.B);
+        if (out_f32) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, float, DQK, DV, DROP, 2>), grid, dim3(ANT), 0, st, p);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, T, DQK, DV, DROP, 2>), grid, dim3(ANT), 0, st, p);
+        return dcc_check_launch();
+      }
+    }
+#endif
     dim3 grid(((p.Nk + 127) / 128) * p.qsplit, p.H, p.B);
-    if (out_f32) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, float, DQK, DV, DROP>), grid, dim3(ANT), 0, st, p);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, T, DQK, DV, DROP>), grid, dim3(ANT), 0, st, p);
+    if (out_f32) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, float, DQK, DV, DROP, 1>), grid, dim3(ANT), 0, st, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, T, DQK, DV, DROP, 1>), grid, dim3(ANT), 0, st, p);
   }
   return dcc_check_launch();
 }

@@ -7,7 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "deepcoro_clip_amd", "csrc")
 src, pat, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
 out = "/tmp/isa_sched.s"
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-result", "-ffp-contract=fast", "-I", CSRC,
+sys.path.insert(0, ROOT)
+from deepcoro_clip_amd.build import FILE_FLAGS  # the per-file flags of the real build (e.g. attention.hip: MFMA in VGPR form)
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-result", "-ffp-contract=fast", *FILE_FLAGS.get(src, []), "-I", CSRC,
        "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out, *extra]
 r = subprocess.run(cmd, capture_output=True, text=True)
 if r.returncode:
@@ -33,15 +35,17 @@ for f in re.split(r"\n(?=_Z\w+:)", s):
         else:
             cur.append(l)
     blocks.append((bn, cur))
-    bn, b = max(blocks, key=lambda t: sum("v_mfma" in l for l in t[1]))
-    ops = [l.split()[0] for l in b if l.strip() and not l.strip().startswith((";", "."))]
-    outl, prev, c = [], None, 0
-    for o in ops:
-        o = SHORT.get(o, o)
-        if o == prev: c += 1
-        else:
-            if prev: outl.append(f"{prev}x{c}" if c > 1 else prev)
-            prev, c = o, 1
-    outl.append(f"{prev}x{c}" if c > 1 else prev)
-    print(" ", bn, len(b), "lines,", sum("v_mfma" in l for l in b), "MFMAs:")
-    print("  " + " ".join(outl))
+    top = sorted(blocks, key=lambda t: -sum("v_mfma" in l for l in t[1]))
+    nshow = int(os.environ.get("ISA_BLOCKS", "1"))
+    for bn, b in top[:nshow]:
+        ops = [l.split()[0] for l in b if l.strip() and not l.strip().startswith((";", "."))]
+        outl, prev, c = [], None, 0
+        for o in ops:
+            o = SHORT.get(o, o)
+            if o == prev: c += 1
+            else:
+                if prev: outl.append(f"{prev}x{c}" if c > 1 else prev)
+                prev, c = o, 1
+        outl.append(f"{prev}x{c}" if c > 1 else prev)
+        print(" ", bn, len(b), "lines,", sum("v_mfma" in l for l in b), "MFMAs:")
+        print("  " + " ".join(outl))
