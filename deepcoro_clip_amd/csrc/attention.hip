@@ -165,9 +165,8 @@ __device__ __forceinline__ frag_t<T> row_frag(const char* lds, int t0, int s, in
 
 // transposed fragment matching acc_as_frag's k order: element j of lane (r,h) =
 //   tile[row = t0 + 16*s2 + 8*(j>>2) + 4*h + (j&3)][col = c0 + r]
-template <typename T, int D>
+template <typename T, int D, int PITCH = RowTile<T, D>::PITCH>
 __device__ __forceinline__ frag_t<T> tr_frag(const char* lds, int t0, int s2, int c0, int lane) {
-  using RT = RowTile<T, D>;
   const int r = lane & 31, h = lane >> 5;
   frag_t<T> f;
   if constexpr (sizeof(T) == 2) {
@@ -175,7 +174,7 @@ __device__ __forceinline__ frag_t<T> tr_frag(const char* lds, int t0, int s2, in
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int row = t0 + 16 * s2 + 8 * half + 4 * h + q;
-      const char* p = lds + row * RT::PITCH + (c0 + 16 * g + 4 * pp) * 2;
+      const char* p = lds + row * PITCH + (c0 + 16 * g + 4 * pp) * 2;
       const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
       const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
       f[4 * half + 0] = tb[0]; f[4 * half + 1] = tb[1]; f[4 * half + 2] = tb[2]; f[4 * half + 3] = tb[3];
@@ -184,7 +183,7 @@ __device__ __forceinline__ frag_t<T> tr_frag(const char* lds, int t0, int s2, in
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int row = t0 + 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3);
-      f[j] = *reinterpret_cast<const float*>(lds + row * RT::PITCH + (c0 + r) * 4);
+      f[j] = *reinterpret_cast<const float*>(lds + row * PITCH + (c0 + r) * 4);
     }
   }
   return f;
@@ -787,7 +786,15 @@ struct PipeGeo {
   using QT = RowTile<bf16_t, DQK>;
   using OT = RowTile<bf16_t, DV>;
   static constexpr int Q_BYTES = PT * QT::PITCH, O_BYTES = PT * OT::PITCH;
-  static constexpr int TILE_BYTES = Q_BYTES + O_BYTES + 2 * PT * 4;
+  // Second copy of the tile for the transposed reads.  A ds_read_b64_tr_b16 takes 4 consecutive rows x 64 bytes per 32 lanes: the
+  // rows must start 64 bytes apart modulo 256 (the 64 banks) to be conflict-free, while the row reads (16 rows x one 16-byte column
+  // per 16 lanes) want a pitch of an odd number of 16-byte units — no single pitch serves both, so the tile is kept twice (PMC: the
+  // padded single copy spent more LDS cycles on bank conflicts than on data).
+  static constexpr int QTR_PITCH = ((DQK * 2 + 255) / 256) * 256 + 64 - ((DQK * 2) % 256 == 64 ? 256 : 0);
+  static constexpr int OTR_PITCH = DV * 2 == 192 ? 192 : ((DV * 2 + 255) / 256) * 256 + 64;
+  static_assert(QTR_PITCH >= DQK * 2 && QTR_PITCH % 256 == 64 && (OTR_PITCH % 256 == 64 || OTR_PITCH % 256 == 192), "transposed-read pitch");
+  static constexpr int QTR_OFF = Q_BYTES + O_BYTES, OTR_OFF = QTR_OFF + PT * QTR_PITCH, LD_OFF = OTR_OFF + PT * OTR_PITCH;
+  static constexpr int TILE_BYTES = LD_OFF + 2 * PT * 4;
   static constexpr int TPITCH = DQK + 4;
   static constexpr int TRANS_BYTES = 4 * 32 * TPITCH * 4;
   static constexpr int LDS_BYTES = PNBUF * TILE_BYTES > TRANS_BYTES ? PNBUF * TILE_BYTES : TRANS_BYTES;
@@ -845,51 +852,56 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
 
   const __amdgpu_buffer_rsrc_t rsQ = tile_rsrc<T, DQK>(Q, p.sqn, p.Nq), rsO = tile_rsrc<T, DV>(dO, p.son, p.Nq);
   const int qstride = (int)p.sqn * 2, ostride = (int)p.son * 2;
-  vec16_t<T> rq[G::RQ], ro[G::RO];
-  float rl = 0.0f;
-  auto gload = [&](int j) {  // global -> registers, tile j of this block
+  // Two register sets: a tile's loads are issued two iterations before its LDS writes (HBM / L2 latency under load is well over one
+  // iteration).  Loads and LDS writes are branch-free — chunk ids past the tile are clamped (two threads then write the same bytes to
+  // the same place), tiles past the block's range are clamped to its last tile and land in a buffer nobody reads — so that the tail of
+  // an iteration is straight-line code and the compiler's vmcnt bookkeeping can leave the younger set's loads in flight (with
+  // predicated loads it fell back to vmcnt(0) at every join).  (Hand-counted waits on inline-asm loads were tried: the register
+  // allocator may copy a loaded register before the data has landed — it does at the loop's phis — so the loads stay builtins.)
+  vec16_t<T> rq[2][G::RQ], ro[2][G::RO];
+  float rl[2] = {0.0f, 0.0f};
+  const float* ldsrc = (tid & 32) ? Dv : LSE;   // lanes 0..31 of a wave: LSE, 32..63: D
+  auto gload = [&](auto setc, int j) {  // global -> registers of set SET, tile min(j, n - 1) of this block
+    constexpr int SET = decltype(setc)::value;
+    if (j > n - 1) j = n - 1;
     const int row0 = (qt_begin + j) * PT;
 #pragma unroll
     for (int i = 0; i < G::RQ; ++i) {
-      const int id = tid + ANT * i;
-      if (G::NQ % ANT == 0 || id < G::NQ) {
-        const int rr = id / QT::CPR, c = id % QT::CPR;
-        rq[i] = __builtin_bit_cast(vec16_t<T>, __builtin_amdgcn_raw_buffer_load_b128(rsQ, (row0 + rr) * qstride + c * 16, 0, 0));
-      }
+      int id = tid + ANT * i; if (id > G::NQ - 1) id = G::NQ - 1;
+      const int rr = id / QT::CPR, c = id % QT::CPR;
+      rq[SET][i] = __builtin_bit_cast(vec16_t<T>, __builtin_amdgcn_raw_buffer_load_b128(rsQ, (row0 + rr) * qstride + c * 16, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < G::RO; ++i) {
-      const int id = tid + ANT * i;
-      if (G::NO % ANT == 0 || id < G::NO) {
-        const int rr = id / OT::CPR, c = id % OT::CPR;
-        ro[i] = __builtin_bit_cast(vec16_t<T>, __builtin_amdgcn_raw_buffer_load_b128(rsO, (row0 + rr) * ostride + c * 16, 0, 0));
-      }
+      int id = tid + ANT * i; if (id > G::NO - 1) id = G::NO - 1;
+      const int rr = id / OT::CPR, c = id % OT::CPR;
+      ro[SET][i] = __builtin_bit_cast(vec16_t<T>, __builtin_amdgcn_raw_buffer_load_b128(rsO, (row0 + rr) * ostride + c * 16, 0, 0));
     }
-    if (tid < 2 * PT) {  // lanes 0..31: LSE (log2 units), lanes 32..63: D
-      const int q = row0 + (tid & (PT - 1));
-      if (tid < PT) rl = (q < p.Nq) ? LSE[q] * LOG2E : INFINITY;
-      else rl = (q < p.Nq) ? Dv[q] : 0.0f;
-    }
+    int q = row0 + (tid & (PT - 1)); if (q > p.Nq - 1) q = p.Nq - 1;
+    rl[SET] = ldsrc[q];
   };
-  auto lstore = [&](int j) {  // registers -> LDS buffer of tile j
+  auto lstore = [&](auto setc, int j) {  // registers of set SET -> LDS buffer of tile j (both copies)
+    constexpr int SET = decltype(setc)::value;
     char* base = psmem + (j & (PNBUF - 1)) * G::TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < G::RQ; ++i) {
-      const int id = tid + ANT * i;
-      if (G::NQ % ANT == 0 || id < G::NQ) {
-        const int rr = id / QT::CPR, c = id % QT::CPR;
-        *reinterpret_cast<vec16_t<T>*>(base + rr * QT::PITCH + c * 16) = rq[i];
-      }
+      int id = tid + ANT * i; if (id > G::NQ - 1) id = G::NQ - 1;
+      const int rr = id / QT::CPR, c = id % QT::CPR;
+      *reinterpret_cast<vec16_t<T>*>(base + rr * QT::PITCH + c * 16) = rq[SET][i];
+      *reinterpret_cast<vec16_t<T>*>(base + G::QTR_OFF + rr * G::QTR_PITCH + c * 16) = rq[SET][i];
     }
 #pragma unroll
     for (int i = 0; i < G::RO; ++i) {
-      const int id = tid + ANT * i;
-      if (G::NO % ANT == 0 || id < G::NO) {
-        const int rr = id / OT::CPR, c = id % OT::CPR;
-        *reinterpret_cast<vec16_t<T>*>(base + G::Q_BYTES + rr * OT::PITCH + c * 16) = ro[i];
-      }
+      int id = tid + ANT * i; if (id > G::NO - 1) id = G::NO - 1;
+      const int rr = id / OT::CPR, c = id % OT::CPR;
+      *reinterpret_cast<vec16_t<T>*>(base + G::Q_BYTES + rr * OT::PITCH + c * 16) = ro[SET][i];
+      *reinterpret_cast<vec16_t<T>*>(base + G::OTR_OFF + rr * G::OTR_PITCH + c * 16) = ro[SET][i];
     }
-    if (tid < 2 * PT) reinterpret_cast<float*>(base + G::Q_BYTES + G::O_BYTES)[tid] = rl;
+    // every wave writes the tile's 32 LSE (log2 units; +inf past Nq: P = 0) and 32 D values
+    const int jj = j > n - 1 ? n - 1 : j;
+    const bool valid = (qt_begin + jj) * PT + (tid & (PT - 1)) < p.Nq;
+    const float v = rl[SET];
+    reinterpret_cast<float*>(base + G::LD_OFF)[tid & 63] = (tid & 32) ? (valid ? v : 0.0f) : (valid ? v * LOG2E : INFINITY);
   };
   auto phaseA = [&](int j, f32x16& S, f32x16& dP) {
     const char* base = psmem + (j & (PNBUF - 1)) * G::TILE_BYTES;
@@ -901,7 +913,7 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
     for (int s = 0; s < DV / 16; ++s) dP = mma16(row_frag<T, DV>(base + G::Q_BYTES, 0, s, lane), vf[s], dP);
   };
   auto phaseB = [&](int j, const f32x16& S, const f32x16& dP, frag_t<T>* pf, frag_t<T>* zf) {
-    const float* ld = reinterpret_cast<const float*>(psmem + (j & (PNBUF - 1)) * G::TILE_BYTES + G::Q_BYTES + G::O_BYTES);
+    const float* ld = reinterpret_cast<const float*>(psmem + (j & (PNBUF - 1)) * G::TILE_BYTES + G::LD_OFF);
     f32x16 P, Z;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -923,9 +935,9 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-      for (int t = 0; t < DV / 32; ++t) mma16_acc_retired(dvv[t], tr_frag<T, DV>(base + G::Q_BYTES, 0, s2, 32 * t, lane), pf[s2]);
+      for (int t = 0; t < DV / 32; ++t) mma16_acc_retired(dvv[t], tr_frag<T, DV, G::OTR_PITCH>(base + G::OTR_OFF, 0, s2, 32 * t, lane), pf[s2]);
 #pragma unroll
-      for (int t = 0; t < DQK / 32; ++t) mma16_acc_retired(dk[t], tr_frag<T, DQK>(base, 0, s2, 32 * t, lane), zf[s2]);
+      for (int t = 0; t < DQK / 32; ++t) mma16_acc_retired(dk[t], tr_frag<T, DQK, G::QTR_PITCH>(base + G::QTR_OFF, 0, s2, 32 * t, lane), zf[s2]);
     }
   };
 
@@ -942,10 +954,10 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
         constexpr int NCH = DV / 32 + DQK / 32, NC = 2 * NCH, NA = DQK / 16 + DV / 16, NS = NC + NA, AHEAD = 3;
         const uint32_t lbase = (uint32_t)(uintptr_t)LDS_PTR(const char, psmem);
         const uint32_t bC = lbase + ((j - 1) & (PNBUF - 1)) * G::TILE_BYTES, bA = lbase + ((j + 1) & (PNBUF - 1)) * G::TILE_BYTES;
-        const uint32_t bB = lbase + (j & (PNBUF - 1)) * G::TILE_BYTES + G::Q_BYTES + G::O_BYTES;
+        const uint32_t bB = lbase + (j & (PNBUF - 1)) * G::TILE_BYTES + G::LD_OFF;
         const int i16 = lane & 15, tq = i16 >> 2, tpp = i16 & 3, tg = (lane >> 4) & 1;
-        const uint32_t trQ = bC + (4 * h + tq) * QT::PITCH + (16 * tg + 4 * tpp) * 2;
-        const uint32_t trO = bC + G::Q_BYTES + (4 * h + tq) * OT::PITCH + (16 * tg + 4 * tpp) * 2;
+        const uint32_t trQ = bC + G::QTR_OFF + (4 * h + tq) * G::QTR_PITCH + (16 * tg + 4 * tpp) * 2;
+        const uint32_t trO = bC + G::OTR_OFF + (4 * h + tq) * G::OTR_PITCH + (16 * tg + 4 * tpp) * 2;
         const uint32_t rwQ = bA + (lane & 31) * QT::PITCH + 16 * h;
         const uint32_t rwO = bA + G::Q_BYTES + (lane & 31) * OT::PITCH + 16 * h;
         const uint32_t ldL = bB + 16 * h;
@@ -956,11 +968,11 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
           if constexpr (k < NC) {
             constexpr int s2 = k / NCH, r = k % NCH;
             if constexpr (r < DV / 32) {
-              const u32x2 lo = hlds_tr64<(16 * s2) * OT::PITCH + 64 * r>(trO), hi = hlds_tr64<(16 * s2 + 8) * OT::PITCH + 64 * r>(trO);
+              const u32x2 lo = hlds_tr64<(16 * s2) * G::OTR_PITCH + 64 * r>(trO), hi = hlds_tr64<(16 * s2 + 8) * G::OTR_PITCH + 64 * r>(trO);
               fr[k % (AHEAD + 1)] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             } else {
               constexpr int t = r - DV / 32;
-              const u32x2 lo = hlds_tr64<(16 * s2) * QT::PITCH + 64 * t>(trQ), hi = hlds_tr64<(16 * s2 + 8) * QT::PITCH + 64 * t>(trQ);
+              const u32x2 lo = hlds_tr64<(16 * s2) * G::QTR_PITCH + 64 * t>(trQ), hi = hlds_tr64<(16 * s2 + 8) * G::QTR_PITCH + 64 * t>(trQ);
               fr[k % (AHEAD + 1)] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
           } else if constexpr (k < NS) {
@@ -1026,19 +1038,24 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
   };
 
   if (n > 0) {
-    // prologue: tiles 0 and 1 into LDS, A(0); global loads run a whole iteration ahead of their LDS writes
-    gload(0);
-    lstore(0);
-    if (n > 1) { gload(1); lstore(1); }
-    if (n > 2) gload(2);
+    // prologue: tiles 0 and 1 into LDS, A(0); the loads of tile t are issued at the end of iteration t - 4 (set t & 1), its LDS writes
+    // happen at the end of iteration t - 2
+    constexpr std::integral_constant<int, 0> SET0{};
+    constexpr std::integral_constant<int, 1> SET1{};
+    gload(SET0, 0);
+    gload(SET1, 1);
+    lstore(SET0, 0);
+    lstore(SET1, 1);
+    gload(SET0, 2);
+    gload(SET1, 3);
     __syncthreads();
     f32x16 S, dP, Sn, dPn;
     frag_t<T> pf[2], zf[2], pfn[2], zfn[2];
-    // the tail of every iteration: tile j + 2 (loaded during the previous iteration) into LDS, loads of tile j + 3, barrier
-    auto tail = [&](int j) {
+    // the tail of iteration j (set j & 1): tile j + 2 into LDS, loads of tile j + 4, barrier
+    auto tail = [&](auto setc, int j) {
 #ifndef DCC_PIPE_EXP_NOLOAD   // (timing experiment: tiles are not refreshed)
-      if (j + 2 < n) lstore(j + 2);
-      if (j + 3 < n) gload(j + 3);
+      lstore(setc, j + 2);
+      gload(setc, j + 4);
 #endif
       __syncthreads();
     };
@@ -1048,27 +1065,28 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
       phaseB(0, S, dP, pf, zf);
       if (n > 1) phaseA(1, S, dP);
     }
-    tail(0);
+    tail(SET0, 0);
+    // pairs (odd j first): the second iteration of a pair runs with the roles of (S, dP, pf, zf) and (Sn, dPn, pfn, zfn) swapped, so
+    // nothing is copied
     int j = 1;
-    if (j + 1 < n && ((n - 2) & 1)) {  // odd number of steady iterations: the first one compiler-scheduled, the rest in pairs
-      if (active) {
-        phaseC(0, pf, zf);
-        phaseB(1, S, dP, pf, zf);
-        phaseA(2, S, dP);
-      }
-      tail(1);
-      j = 2;
-    }
-    // pairs: the second iteration of a pair runs with the roles of (S, dP, pf, zf) and (Sn, dPn, pfn, zfn) swapped, so nothing is copied
-    for (; j + 1 < n; j += 2) {
+    for (; j + 2 < n; j += 2) {
       if (active) steady(j, S, dP, Sn, dPn, pf, zf, pfn, zfn);
-      tail(j);
+      tail(SET1, j);
       if (active) steady(j + 1, Sn, dPn, S, dP, pfn, zfn, pf, zf);
-      tail(j + 1);
+      tail(SET0, j + 1);
     }
-    // the hand-placed MFMAs' results are invisible to the compiler's hazard tracking: let the last ones retire before vector code reads them
+    // the hand-placed MFMAs' results are invisible to the compiler's hazard tracking: let the last ones retire before compiler-scheduled
+    // vector code reads them
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    if (j + 1 < n) {  // one steady iteration left over (odd j): compiler-scheduled, in place
+      if (active) {
+        phaseC(j - 1, pf, zf);
+        phaseB(j, S, dP, pf, zf);
+        phaseA(j + 1, S, dP);
+      }
+      tail(SET1, j);
+    }
     if (active) {
       if (n > 1) {  // j = n - 1: C(n-2), B(n-1)
         phaseC(n - 2, pf, zf);
@@ -1120,10 +1138,12 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
   }
 }
 
-// DCC_ATTN_PIPE = 1 selects the pipelined dK/dV kernel (A/B runs; off by default until it is the faster one)
-inline bool attn_pipe_enabled() {
-  static const bool on = [] { const char* e = getenv("DCC_ATTN_PIPE"); return e && atoi(e) != 0; }();
-  return on;
+// The pipelined dK/dV kernel pays off once a block streams enough query tiles to amortise its compiler-scheduled first and last
+// iterations (measured: 6 273 and 1 569 queries -8 .. -15 %, 393 queries +-1 %).  DCC_ATTN_PIPE = 0 | 1 forces the choice (A/B runs).
+inline bool attn_pipe_enabled(const AttnParams& p) {
+  static const int forced = [] { const char* e = getenv("DCC_ATTN_PIPE"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  if (forced >= 0) return forced == 1;
+  return p.Nq / p.qsplit >= 768;
 }
 
 template <typename TO, int DQK, int DV>
@@ -1160,7 +1180,7 @@ int launch_attn(int which, const AttnParams& p, int out_f32, hipStream_t st) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DQK, DV, DROP>), grid, dim3(ANT), 0, st, p);
   } else {
     if constexpr (sizeof(T) == 2 && !DROP && DV == 96 && (DQK == 128 || DQK == 160)) {
-      if (attn_pipe_enabled()) return out_f32 ? launch_dkv_pipe<float, DQK, DV>(p, st) : launch_dkv_pipe<bf16_t, DQK, DV>(p, st);
+      if (attn_pipe_enabled(p)) return out_f32 ? launch_dkv_pipe<float, DQK, DV>(p, st) : launch_dkv_pipe<bf16_t, DQK, DV>(p, st);
     }
 #ifdef DCC_ATTN_KW2   // needs AGPR accumulators: build attention.hip without -amdgpu-mfma-vgpr-form
     if constexpr (sizeof(T) == 2 && !DROP) {
