@@ -725,6 +725,9 @@ template <int N, int NDS, int NVALU> __device__ __forceinline__ void sched_slots
 #ifndef DCC_PIPE_DBG
 #define DCC_PIPE_DBG 0
 #endif
+#ifndef PIPE_AHEAD
+#define PIPE_AHEAD 3   // fragments in flight ahead of the MFMA that consumes them
+#endif
 #ifndef PIPE_VALU_C
 #define PIPE_VALU_C 5
 #endif
@@ -779,21 +782,33 @@ __device__ __forceinline__ void mma16_acc(f32x16& acc, const bf16x8& a, const bf
 }
 
 constexpr int PT = 32;     // query rows per pipelined tile
+#ifdef DCC_PIPE_TILE_BARRIER   // (A/B: the earlier schedule, one barrier per tile, four buffers)
 constexpr int PNBUF = 4;
+#else
+constexpr int PNBUF = 8;   // barrier once per pair of tiles: tiles j-1 .. j+2 live, j+3 and j+4 being written
+#endif
 
 template <int DQK, int DV>
 struct PipeGeo {
   using QT = RowTile<bf16_t, DQK>;
   using OT = RowTile<bf16_t, DV>;
   static constexpr int Q_BYTES = PT * QT::PITCH, O_BYTES = PT * OT::PITCH;
-  // Second copy of the tile for the transposed reads.  A ds_read_b64_tr_b16 takes 4 consecutive rows x 64 bytes per 32 lanes: the
-  // rows must start 64 bytes apart modulo 256 (the 64 banks) to be conflict-free, while the row reads (16 rows x one 16-byte column
-  // per 16 lanes) want a pitch of an odd number of 16-byte units — no single pitch serves both, so the tile is kept twice (PMC: the
-  // padded single copy spent more LDS cycles on bank conflicts than on data).
+  // Optional second copy of the tile for the transposed reads.  A ds_read_b64_tr_b16 takes 4 consecutive rows x 64 bytes per 32
+  // lanes: the rows must start 64 bytes apart modulo 256 (the 64 banks) to be conflict-free, while the row reads (16 rows x one
+  // 16-byte column per 16 lanes) want a pitch of an odd number of 16-byte units — no single pitch serves both.  Measured: keeping the
+  // tile twice costs more in LDS writes than the conflicts it removes (attention backward 6.20 vs 6.09 ms per step), so it is off.
+#ifndef DCC_PIPE_DUAL_COPY
+  static constexpr int QTR_PITCH = QT::PITCH, OTR_PITCH = OT::PITCH;
+#else
   static constexpr int QTR_PITCH = ((DQK * 2 + 255) / 256) * 256 + 64 - ((DQK * 2) % 256 == 64 ? 256 : 0);
   static constexpr int OTR_PITCH = DV * 2 == 192 ? 192 : ((DV * 2 + 255) / 256) * 256 + 64;
   static_assert(QTR_PITCH >= DQK * 2 && QTR_PITCH % 256 == 64 && (OTR_PITCH % 256 == 64 || OTR_PITCH % 256 == 192), "transposed-read pitch");
+#endif
+#ifndef DCC_PIPE_DUAL_COPY   // default: transposed reads from the row copy (DCC_PIPE_DUAL_COPY: A/B builds of the second copy)
+  static constexpr int QTR_OFF = 0, OTR_OFF = Q_BYTES, LD_OFF = Q_BYTES + O_BYTES;
+#else
   static constexpr int QTR_OFF = Q_BYTES + O_BYTES, OTR_OFF = QTR_OFF + PT * QTR_PITCH, LD_OFF = OTR_OFF + PT * OTR_PITCH;
+#endif
   static constexpr int TILE_BYTES = LD_OFF + 2 * PT * 4;
   static constexpr int TPITCH = DQK + 4;
   static constexpr int TRANS_BYTES = 4 * 32 * TPITCH * 4;
@@ -888,14 +903,14 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
       int id = tid + ANT * i; if (id > G::NQ - 1) id = G::NQ - 1;
       const int rr = id / QT::CPR, c = id % QT::CPR;
       *reinterpret_cast<vec16_t<T>*>(base + rr * QT::PITCH + c * 16) = rq[SET][i];
-      *reinterpret_cast<vec16_t<T>*>(base + G::QTR_OFF + rr * G::QTR_PITCH + c * 16) = rq[SET][i];
+      if constexpr (G::QTR_OFF != 0) *reinterpret_cast<vec16_t<T>*>(base + G::QTR_OFF + rr * G::QTR_PITCH + c * 16) = rq[SET][i];
     }
 #pragma unroll
     for (int i = 0; i < G::RO; ++i) {
       int id = tid + ANT * i; if (id > G::NO - 1) id = G::NO - 1;
       const int rr = id / OT::CPR, c = id % OT::CPR;
       *reinterpret_cast<vec16_t<T>*>(base + G::Q_BYTES + rr * OT::PITCH + c * 16) = ro[SET][i];
-      *reinterpret_cast<vec16_t<T>*>(base + G::OTR_OFF + rr * G::OTR_PITCH + c * 16) = ro[SET][i];
+      if constexpr (G::QTR_OFF != 0) *reinterpret_cast<vec16_t<T>*>(base + G::OTR_OFF + rr * G::OTR_PITCH + c * 16) = ro[SET][i];
     }
     // every wave writes the tile's 32 LSE (log2 units; +inf past Nq: P = 0) and 32 D values
     const int jj = j > n - 1 ? n - 1 : j;
@@ -951,7 +966,7 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
 #endif
         // NC + NA slots, one MFMA each: slot k issues the LDS reads of the fragment of slot k + AHEAD, waits for its own, then runs
         // its MFMA and its share of B(j)
-        constexpr int NCH = DV / 32 + DQK / 32, NC = 2 * NCH, NA = DQK / 16 + DV / 16, NS = NC + NA, AHEAD = 3;
+        constexpr int NCH = DV / 32 + DQK / 32, NC = 2 * NCH, NA = DQK / 16 + DV / 16, NS = NC + NA, AHEAD = PIPE_AHEAD;
         const uint32_t lbase = (uint32_t)(uintptr_t)LDS_PTR(const char, psmem);
         const uint32_t bC = lbase + ((j - 1) & (PNBUF - 1)) * G::TILE_BYTES, bA = lbase + ((j + 1) & (PNBUF - 1)) * G::TILE_BYTES;
         const uint32_t bB = lbase + (j & (PNBUF - 1)) * G::TILE_BYTES + G::LD_OFF;
@@ -983,13 +998,17 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
         };
         // LDS operations issued for slot k's fragment (what a wait on an older fragment must leave outstanding)
         auto nops = [](int k) constexpr { return k < NC ? 2 : (k < NS ? 1 : 0); };
+        auto younger = [nops](int k) constexpr { int t = 0; for (int i = 1; i < AHEAD; ++i) t += nops(k + i); return t; };
+        // S and dP are results of the previous iteration's hand-written MFMAs, whose latency the compiler does not know: nothing may
+        // read S before this point (its chain ended six MFMAs before the end of that iteration) nor dP before slot 16 (below)
+        asm volatile("" : "+v"(S));
         __builtin_amdgcn_sched_barrier(0);
         static_for<4>([&](auto gc) { constexpr int g = decltype(gc)::value; l4[g] = hlds_b128<32 * g>(ldL); d4[g] = hlds_b128<PT * 4 + 32 * g>(ldL); });
         static_for<AHEAD>([&](auto kc) { issue(kc); });
         static_for<NS>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           // wait first, then issue: at most 8 (L / D) + 2 * AHEAD operations are ever outstanding, within the 4-bit counter
-          hwait<nops(k + 1) + nops(k + 2)>(fr[k % (AHEAD + 1)]);
+          hwait<younger(k)>(fr[k % (AHEAD + 1)]);
           issue(std::integral_constant<int, k + AHEAD>{});
           __builtin_amdgcn_sched_barrier(0);
           const bf16x8 a = __builtin_bit_cast(bf16x8, fr[k % (AHEAD + 1)]);
@@ -1018,15 +1037,19 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
             asm volatile("" : "+v"(S[k]));
           } else if constexpr (k < 24) {
             constexpr int e = 2 * (k - 16);
+            if constexpr (k == 16) asm volatile("" : "+v"(dP));
             dP[e] = S[e] * (dP[e] - u2f(d4[e >> 2][e & 3]));
             dP[e + 1] = S[e + 1] * (dP[e + 1] - u2f(d4[(e + 1) >> 2][(e + 1) & 3]));
             bf16x2 c; c[0] = (bf16_t)S[e]; c[1] = (bf16_t)S[e + 1];
             pfn[e >> 3][e & 7] = c[0]; pfn[e >> 3][(e & 7) + 1] = c[1];
-            asm volatile("" : "+v"(dP[e]), "+v"(dP[e + 1]));
+            // pinned here: a conversion that sinks to just before the (inline-asm) MFMA reading it would need wait states the compiler
+            // does not know to insert
+            asm volatile("" : "+v"(dP[e]), "+v"(dP[e + 1]), "+v"(pfn[e >> 3]));
           } else if constexpr (k < 28) {
             constexpr int e0 = 4 * (k - 24);
 #pragma unroll
             for (int i = 0; i < 4; ++i) zfn[(e0 + i) >> 3][(e0 + i) & 7] = (bf16_t)dP[e0 + i];
+            asm volatile("" : "+v"(zfn[e0 >> 3]));
           }
           __builtin_amdgcn_sched_barrier(0);
         });
@@ -1042,6 +1065,7 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
     // happen at the end of iteration t - 2
     constexpr std::integral_constant<int, 0> SET0{};
     constexpr std::integral_constant<int, 1> SET1{};
+#ifdef DCC_PIPE_TILE_BARRIER
     gload(SET0, 0);
     gload(SET1, 1);
     lstore(SET0, 0);
@@ -1053,10 +1077,8 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
     frag_t<T> pf[2], zf[2], pfn[2], zfn[2];
     // the tail of iteration j (set j & 1): tile j + 2 into LDS, loads of tile j + 4, barrier
     auto tail = [&](auto setc, int j) {
-#ifndef DCC_PIPE_EXP_NOLOAD   // (timing experiment: tiles are not refreshed)
       lstore(setc, j + 2);
       gload(setc, j + 4);
-#endif
       __syncthreads();
     };
     // j = 0: B(0), A(1)
@@ -1075,6 +1097,46 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
       if (active) steady(j + 1, Sn, dPn, S, dP, pfn, zfn, pf, zf);
       tail(SET0, j + 1);
     }
+    constexpr bool LEFTOVER_TAIL = true;
+#else
+    // tiles 0 .. 3 into LDS (even tiles through set 0, odd through set 1), loads of tiles 4 and 5 in flight; then one barrier per PAIR
+    // of iterations: the pair (j, j+1) reads tiles j-1 .. j+2, its tail writes tiles j+3, j+4 (loaded during the previous pair) and
+    // issues the loads of j+5, j+6.  Eight buffers, so a wave still in iteration j never sees its tiles overwritten.
+    gload(SET0, 0);
+    gload(SET1, 1);
+    lstore(SET0, 0);
+    lstore(SET1, 1);
+    gload(SET0, 2);
+    gload(SET1, 3);
+    lstore(SET0, 2);
+    lstore(SET1, 3);
+    gload(SET0, 4);
+    gload(SET1, 5);
+    __syncthreads();
+    f32x16 S, dP, Sn, dPn;
+    frag_t<T> pf[2], zf[2], pfn[2], zfn[2];
+    if (active) {  // j = 0: B(0), A(1)
+      phaseA(0, S, dP);
+      phaseB(0, S, dP, pf, zf);
+      if (n > 1) phaseA(1, S, dP);
+    }
+    // pairs (odd j first): the second iteration of a pair runs with the roles of (S, dP, pf, zf) and (Sn, dPn, pfn, zfn) swapped, so
+    // nothing is copied
+    int j = 1;
+    for (; j + 2 < n; j += 2) {
+      if (active) {
+        steady(j, S, dP, Sn, dPn, pf, zf, pfn, zfn);
+        steady(j + 1, Sn, dPn, S, dP, pfn, zfn, pf, zf);
+      }
+      lstore(SET0, j + 3);
+      lstore(SET1, j + 4);
+      gload(SET0, j + 5);
+      gload(SET1, j + 6);
+      __syncthreads();
+    }
+    constexpr bool LEFTOVER_TAIL = false;
+    auto tail = [&](auto, int) {};
+#endif
     // the hand-placed MFMAs' results are invisible to the compiler's hazard tracking: let the last ones retire before compiler-scheduled
     // vector code reads them
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -1085,7 +1147,7 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
         phaseB(j, S, dP, pf, zf);
         phaseA(j + 1, S, dP);
       }
-      tail(SET1, j);
+      if constexpr (LEFTOVER_TAIL) tail(SET1, j);
     }
     if (active) {
       if (n > 1) {  // j = n - 1: C(n-2), B(n-1)

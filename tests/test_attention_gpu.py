@@ -31,6 +31,10 @@ CASES = [
     (3, 12, 32, 32, 64, 64, True, False),
     (2, 8, 1, 393, 64, 64, False, False),
     (2, 4, 8, 8, 128, 128, False, False),
+    # long query ranges: the software-pipelined dK/dV kernel (blocks streaming >= 768 queries), even and odd tile counts
+    (1, 2, 1000, 200, 128, 96, False, True),
+    (1, 1, 1030, 393, 160, 96, False, False),
+    (1, 1, 801, 40, 128, 96, True, True),
 ]
 
 

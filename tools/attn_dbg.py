@@ -19,8 +19,7 @@ def run():
 if len(sys.argv) > 2:
     run()
 else:
-    for tile in ('0,1', '1,2', '2,3', '0,2', '1,3', '0,3', '0,1,2', '1,2,3'):
-      shape = ["1", "1", "128", "32", "128", "96"]
+    for tile, shape in (('', ["1", "1", str(nq), "32", "128", "96"]) for nq in (128, 160, 192, 224, 256, 288, 300, 320)):
       os.environ["DBG_TILE"] = str(tile); print("tile", tile)
       if True:
         for tag, env in (("pipe", "1"), ("base", "0")):
