@@ -734,6 +734,10 @@ template <int N, int NDS, int NVALU> __device__ __forceinline__ void sched_slots
 #ifndef PIPE_VALU_A
 #define PIPE_VALU_A 3
 #endif
+// An inline-asm MFMA is opaque to the compiler's hazard recognizer: a vector instruction that writes one of its operands right in front
+// of it (a conversion that sank, an accumulator-register read-back of a parked K fragment, a zeroing move) needs wait states nobody
+// inserts — the MFMA then reads the register's previous contents.  Two wait states in front of every hand-written MFMA.
+#define PIPE_PRE "s_nop 1\n\t"
 #ifdef DCC_ATTN_PIPE_NOPS
 #define PIPE_NOPS "\n\ts_nop 15\n\ts_nop 3"
 #else
@@ -742,10 +746,10 @@ template <int N, int NDS, int NVALU> __device__ __forceinline__ void sched_slots
 // the same with the result retired when the statement ends: for the compiler-scheduled prologue / epilogue code, where the register
 // allocator may copy an accumulator tuple right behind the MFMA (it does not know the statement's latency)
 __device__ __forceinline__ void mma16_acc_retired(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+a"(acc) : "v"(a), "v"(b));
+  asm volatile(PIPE_PRE "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+a"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mma16_vacc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" PIPE_NOPS : "+v"(acc) : "v"(a), "v"(b));
+  asm volatile(PIPE_PRE "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" PIPE_NOPS : "+v"(acc) : "v"(a), "v"(b));
 }
 // NB: __builtin_bit_cast applied directly to a vector ELEMENT (v[i]) reads element 0 whatever i is (hipcc 7.2): go through a scalar
 __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
@@ -753,7 +757,7 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(flo
 // states between the last move and the MFMA that the compiler cannot know to insert for an inline-asm MFMA: the MFMA then reads the
 // registers' previous contents.)
 __device__ __forceinline__ void mma16_vinit(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" PIPE_NOPS : "=&v"(acc) : "v"(a), "v"(b));
+  asm volatile(PIPE_PRE "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" PIPE_NOPS : "=&v"(acc) : "v"(a), "v"(b));
 }
 // ---- hand-placed pieces of the pipelined kernel's steady state (the compiler neither counts nor waits for these LDS reads)
 template <int N, typename F, int I = 0>
@@ -778,7 +782,7 @@ template <int N> __device__ __forceinline__ void hwait(u32x4& f) { asm volatile(
 // dK / dV accumulate in AGPRs: the kernel is built with MFMA results in VGPRs (the softmax reads S and dP), and 112 more VGPRs
 // of accumulators would leave no room for the second S / dP pair and the fragments in flight
 __device__ __forceinline__ void mma16_acc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" PIPE_NOPS : "+a"(acc) : "v"(a), "v"(b));
+  asm volatile(PIPE_PRE "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" PIPE_NOPS : "+a"(acc) : "v"(a), "v"(b));
 }
 
 constexpr int PT = 32;     // query rows per pipelined tile
