@@ -17,3 +17,12 @@ def test_attention_cases_with_pipelined_kernel_forced(force):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_attention_gpu.py"), "-q", "-m", "gpu", "-x",
                         "-k", "test_attention_fwd_bwd", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_pipelined_kernel_matches_unpipelined_on_random_shapes(tmp_path):
+    """Same summation order, so bit-exact when the query range is not split (tools/attn_pipe_fuzz.py: 24 random shapes, D = 128 / 160,
+    1 .. 1400 queries, 1 .. 450 keys, query splits 1 / 2 / 3 / 5, with and without the residual-pooling shortcut)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import attn_pipe_fuzz
+
+    assert attn_pipe_fuzz.compare(n=24, tmp=str(tmp_path)) == []
