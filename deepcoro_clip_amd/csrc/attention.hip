@@ -52,7 +52,7 @@ constexpr float LN2 = 0.6931471805599453f;
 constexpr int ANT = 256;  // threads per block
 // minimum waves per SIMD the register allocation must leave room for (hipcc otherwise spends up to 512 registers per lane)
 #ifndef DCC_ATTN_OCC_FWD
-#define DCC_ATTN_OCC_FWD 1
+#define DCC_ATTN_OCC_FWD 2   // measured: 168 instead of 180 registers at D = 128 / 96, three waves per SIMD, forward -3.5 % (profiles/r04_attn_pipe_bench.txt, occ2)
 #endif
 #ifndef DCC_ATTN_OCC_DQ
 #define DCC_ATTN_OCC_DQ 1
