@@ -383,7 +383,9 @@ __global__ __launch_bounds__(ANT, DCC_ATTN_OCC_FWD) void attn_fwd_kernel(AttnPar
 // ------------------------------------------------------------------------------------------
 // dQ: same decomposition as the forward (queries on lanes).
 template <typename T, int DQK, int DV, bool DROP>
-__global__ __launch_bounds__(ANT, DCC_ATTN_OCC_DQ) void attn_bwd_dq_kernel(AttnParams p) {
+// DQK = 160 needs 266 registers left alone (one wave per SIMD); capped at 256 it spills 14 dwords outside the key loop and runs two:
+// measured -7 ... -9 % on the three D = 160 shapes of the step (the D = 128 kernels, 238 registers, already hold two)
+__global__ __launch_bounds__(ANT, (DQK >= 160 && sizeof(T) == 2 && !DROP ? 2 : DCC_ATTN_OCC_DQ)) void attn_bwd_dq_kernel(AttnParams p) {
   using KT = RowTile<T, DQK>;
   using VT = RowTile<T, DV>;
   __shared__ __attribute__((aligned(16))) char smem[TK * KT::PITCH + TK * VT::PITCH + TK * 4];

@@ -5,6 +5,18 @@
 // Tokens are [B, N, H, C] views (strides in elements, C contiguous); token 0 is the class token
 // when has_cls != 0 and bypasses the pooling; the remaining tokens form a (T, Hs, Ws) grid.
 #include "common.h"
+
+// Minimum waves per SIMD the register allocation must leave room for (A/B builds: -DDW3_RUN_OCC=n ...).  hipcc allocates up to 512
+// registers per lane for a 256-thread kernel when nothing asks for more waves.
+#ifndef DW3_RUN_OCC
+#define DW3_RUN_OCC 1
+#endif
+#ifndef DW3_BWD_WIDE_OCC
+#define DW3_BWD_WIDE_OCC 1
+#endif
+#ifndef DW3_WGRAD_MARCH_OCC
+#define DW3_WGRAD_MARCH_OCC 1
+#endif
 #include <stdlib.h>
 
 namespace {
@@ -593,7 +605,7 @@ __device__ __forceinline__ RunPos run_pos(unsigned run, const RunGeom& r, int WT
 
 // forward (x = input, y = output) or stride-1 data gradient (MIRROR: x = dy, y = dx, taps mirrored)
 template <typename T, typename TD, int S, int WT, bool MIRROR>
-__global__ __launch_bounds__(256) void dw3_run_kernel(const TD* __restrict__ x, T* __restrict__ y,
+__global__ __launch_bounds__(256, (S == 1 && sizeof(TD) == 2 ? DW3_RUN_OCC : 1)) void dw3_run_kernel(const TD* __restrict__ x, T* __restrict__ y,
                                                       const float* __restrict__ w, RunGeom r) {
   constexpr int CV = Vec16<T>::N;
   constexpr int SEG = (WT - 1) * S + 3;
@@ -1098,7 +1110,7 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_s2_kernel(const TD* __restri
 // columns (S * WQ input columns): 3 dy loads (one per temporal tap) give the 3 non-zero columns of a group, the rest
 // of the row segment is zero-filled — the kernel is a streaming write of dx.
 template <typename T, typename TD, int S, int WQ>
-__global__ __launch_bounds__(256) void dw3_bwd_data_wide_kernel(const TD* __restrict__ dy, T* __restrict__ dx,
+__global__ __launch_bounds__(256, DW3_BWD_WIDE_OCC) void dw3_bwd_data_wide_kernel(const TD* __restrict__ dy, T* __restrict__ dx,
                                                                 const float* __restrict__ w, RunGeom r) {
   static_assert(S >= 4 && (S & (S - 1)) == 0, "non-overlapping windows");
   constexpr int CV = Vec16<T>::N;
@@ -1424,7 +1436,7 @@ __global__ __launch_bounds__(256) void dw3_wgrad_kernel(const TD* __restrict__ d
 // 16 loads per (output run, frame, kh) instead of 34 per (output run, kt).  The next frame's row / dy run are requested
 // before the current frame's FMAs.  Partials: same block fold as dw3_wgrad_kernel (tap = (kt*3 + kh)*3 + kw).
 template <typename T, typename TD, int S, int WT>
-__global__ __launch_bounds__(256) void dw3_wgrad_march_kernel(const TD* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(256, (WT == 2 ? DW3_WGRAD_MARCH_OCC : 1)) void dw3_wgrad_march_kernel(const TD* __restrict__ dy, const T* __restrict__ x,
                                                               float* __restrict__ ws, RunGeom r, int iters, int nruns) {
   constexpr int CV = Vec16<T>::N;
   constexpr int SEG = (WT - 1) * S + 3;

@@ -5,6 +5,10 @@
 // normalised q/k can be written straight into the wider [.. , DQK] attention operand.
 #include "common.h"
 
+#ifndef LN_BWD_OCC
+#define LN_BWD_OCC 1   // minimum waves per SIMD of the LayerNorm backward (A/B builds)
+#endif
+
 namespace {
 
 template <typename T, int LPR, int ITERS>
@@ -117,7 +121,7 @@ template <typename TD, int VEC> __device__ __forceinline__ void unpack_f32(const
 // Parameter gradients: registers over the row loop -> LDS per block -> ONE global atomic per column per block
 // (a few hundred blocks), instead of per-wave global atomics that serialise on C addresses.
 template <typename T, typename TD, int LPR, int ITERS, int U>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const T* __restrict__ x,
+__global__ __launch_bounds__(256, (sizeof(TD) == 2 && ITERS == 1 && U == 4 ? LN_BWD_OCC : 1)) void ln_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const T* __restrict__ x,
                                                      int64_t ldx, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      TD* __restrict__ dx, int64_t lddx, float* __restrict__ dgamma,
