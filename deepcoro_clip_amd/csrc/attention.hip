@@ -1143,18 +1143,20 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
     constexpr bool LEFTOVER_TAIL = false;
     auto tail = [&](auto, int) {};
 #endif
+    if (j + 1 < n && active) {
+      // one steady iteration left over (odd count): the same hand-placed iteration; its results land in the second register set
+      // and are moved once (behind wait states: the compiler does not know the latency of the MFMAs that wrote them)
+      steady(j, S, dP, Sn, dPn, pf, zf, pfn, zfn);
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(Sn), "+v"(dPn));
+      S = Sn; dP = dPn;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) { pf[s2] = pfn[s2]; zf[s2] = zfn[s2]; }
+    }
+    if constexpr (LEFTOVER_TAIL) { if (j + 1 < n) tail(SET1, j); }
     // the hand-placed MFMAs' results are invisible to the compiler's hazard tracking: let the last ones retire before compiler-scheduled
     // vector code reads them
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (j + 1 < n) {  // one steady iteration left over (odd j): compiler-scheduled, in place
-      if (active) {
-        phaseC(j - 1, pf, zf);
-        phaseB(j, S, dP, pf, zf);
-        phaseA(j + 1, S, dP);
-      }
-      if constexpr (LEFTOVER_TAIL) tail(SET1, j);
-    }
     if (active) {
       if (n > 1) {  // j = n - 1: C(n-2), B(n-1)
         phaseC(n - 2, pf, zf);
