@@ -552,7 +552,11 @@ FUSED_MLP_CHANNELS = () if _FUSED_MLP_ENV == "0" else ((96, 192, 384) if _FUSED_
 
 def ln_mlp_ok(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
     C = x.shape[-1]
-    return (C in FUSED_MLP_CHANNELS and x.dtype == torch.bfloat16 and not _FP8["on"] and w1.shape == (4 * C, C)
+    fused = C in FUSED_MLP_CHANNELS
+    if not fused and C == 384 and _FUSED_MLP_ENV != "0":
+        # without the tensors a backward would need (validation / inference()) the fused kernel wins at C = 384 too: 192 vs 212 us
+        fused = not (torch.is_grad_enabled() and (x.requires_grad or w1.requires_grad or w2.requires_grad))
+    return (fused and x.dtype == torch.bfloat16 and not _FP8["on"] and w1.shape == (4 * C, C)
             and w2.shape == (C, 4 * C) and w1.dtype == torch.float32 and w1.is_contiguous() and w2.is_contiguous())
 
 

@@ -168,3 +168,20 @@ def test_weight_image_follows_the_optimizer():
     assert p1 is not p0 and not torch.equal(p0, p1)
     Fn.invalidate_weight_cache()
     assert Fn.wpack_mlp(w1, w2) is not p1
+
+
+def test_c384_is_fused_only_when_no_backward_can_follow():
+    """C = 384 loses with the saved tensors and wins without them: the dispatch follows autograd's state."""
+    from deepcoro_clip_amd import functional as Fn
+
+    if Fn._FUSED_MLP_ENV != "1":
+        pytest.skip("DCC_FUSED_MLP overrides the default dispatch")
+    C = 384
+    x = torch.randn(2, 40, C, device="cuda").bfloat16()
+    w1 = torch.nn.Parameter(torch.randn(4 * C, C, device="cuda") * 0.05)
+    w2 = torch.nn.Parameter(torch.randn(C, 4 * C, device="cuda") * 0.05)
+    assert not Fn.ln_mlp_ok(x, w1, w2)          # training: parameters require grad
+    with torch.no_grad():
+        assert Fn.ln_mlp_ok(x, w1, w2)          # validation / inference()
+    assert Fn.ln_mlp_ok(x, w1.detach(), w2.detach())   # frozen weights, input without grad: nothing to save either
+    assert Fn.ln_mlp_ok(x[..., :192].contiguous(), torch.nn.Parameter(w1[:768, :192].detach().clone()), torch.nn.Parameter(w2[:192, :768].detach().clone()))
