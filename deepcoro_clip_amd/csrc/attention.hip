@@ -1031,19 +1031,22 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
             else if constexpr (q == DQK / 16) mma16_vinit(dPn, a, vf[0]);
             else mma16_vacc(dPn, a, vf[q - DQK / 16]);
           }
-          // B(j): P in slots 0..15, dz pairs in slots 16..23, the bf16 fragments of P in 16..23 and of dz in 24..27
+          // B(j): P[k] in slot k < 16; dz pairs (and the bf16 fragment of P) in the eight slots from ZS; the bf16 fragments of dz in the
+          // four slots from CS.  With 28+ slots (DQK = 128 / 160) the three groups follow each other; with 24 (DQK = 96) the dz pairs
+          // start at slot 12, behind the P they need (pair i needs P[2i], P[2i+1], done by slot 2i + 1 <= 12 + i)
           constexpr bool VAL = DCC_PIPE_DBG != 1;
-          if constexpr (!VAL) {
-          } else if constexpr (k < 16) {
+          constexpr int ZS = NS >= 28 ? 16 : NS - 12, CS = NS >= 28 ? 24 : NS - 4;
+          if constexpr (VAL && k < 16) {
             if constexpr (k == 0) {   // the L / D reads are older than every fragment read: they have landed with fragment 0
 #pragma unroll
               for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(l4[g]), "+v"(d4[g]));
             }
             S[k] = fast_exp2(S[k] * scale2 + kb2 - u2f(l4[k >> 2][k & 3]));
             asm volatile("" : "+v"(S[k]));
-          } else if constexpr (k < 24) {
-            constexpr int e = 2 * (k - 16);
-            if constexpr (k == 16) asm volatile("" : "+v"(dP));
+          }
+          if constexpr (VAL && k >= ZS && k < ZS + 8) {
+            constexpr int e = 2 * (k - ZS);
+            if constexpr (k == ZS) asm volatile("" : "+v"(dP));
             dP[e] = S[e] * (dP[e] - u2f(d4[e >> 2][e & 3]));
             dP[e + 1] = S[e + 1] * (dP[e + 1] - u2f(d4[(e + 1) >> 2][(e + 1) & 3]));
             bf16x2 c; c[0] = (bf16_t)S[e]; c[1] = (bf16_t)S[e + 1];
@@ -1051,8 +1054,9 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
             // pinned here: a conversion that sinks to just before the (inline-asm) MFMA reading it would need wait states the compiler
             // does not know to insert
             asm volatile("" : "+v"(dP[e]), "+v"(dP[e + 1]), "+v"(pfn[e >> 3]));
-          } else if constexpr (k < 28) {
-            constexpr int e0 = 4 * (k - 24);
+          }
+          if constexpr (VAL && k >= CS && k < CS + 4) {
+            constexpr int e0 = 4 * (k - CS);
 #pragma unroll
             for (int i = 0; i < 4; ++i) zfn[(e0 + i) >> 3][(e0 + i) & 7] = (bf16_t)dP[e0 + i];
             asm volatile("" : "+v"(zfn[e0 >> 3]));
@@ -1063,7 +1067,7 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         phaseB(j, S, dP, pfn, zfn);
 #endif
-        static_assert(NS >= 28, "B(j) is spread over 28 slots");
+        static_assert(NS >= 24, "B(j) is spread over at least 24 slots");
   };
 
   if (n > 0) {
@@ -1210,10 +1214,13 @@ __global__ __launch_bounds__(ANT) void attn_bwd_dkv_pipe_kernel(AttnParams p) {
 
 // The pipelined dK/dV kernel pays off once a block streams enough query tiles to amortise its compiler-scheduled first and last
 // iterations (measured: 6 273 and 1 569 queries -8 .. -15 %, 393 queries +-1 %).  DCC_ATTN_PIPE = 0 | 1 forces the choice (A/B runs).
-inline bool attn_pipe_enabled(const AttnParams& p) {
+// DQK = 96 (the RoPE configuration: no rel-pos columns) is built but not selected: its compiler-scheduled kernel needs 248 registers,
+// i.e. already runs two waves per SIMD, and the hand-placed single wave loses to that (32-frame shapes: 15.0 vs 15.7 ms per step,
+// tools/attn_bench_rope.py) — the pipelined form pays exactly where the compiler's form is alone on its SIMD (296 / 324 registers).
+inline bool attn_pipe_enabled(const AttnParams& p, int dqk) {
   static const int forced = [] { const char* e = getenv("DCC_ATTN_PIPE"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
   if (forced >= 0) return forced == 1;
-  return p.Nq / p.qsplit >= 768;
+  return dqk >= 128 && p.Nq / p.qsplit >= 768;
 }
 
 template <typename TO, int DQK, int DV>
@@ -1249,8 +1256,8 @@ int launch_attn(int which, const AttnParams& p, int out_f32, hipStream_t st) {
     dim3 grid((p.Nq + 127) / 128, p.H, p.B);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DQK, DV, DROP>), grid, dim3(ANT), 0, st, p);
   } else {
-    if constexpr (sizeof(T) == 2 && !DROP && DV == 96 && (DQK == 128 || DQK == 160)) {
-      if (attn_pipe_enabled(p)) return out_f32 ? launch_dkv_pipe<float, DQK, DV>(p, st) : launch_dkv_pipe<bf16_t, DQK, DV>(p, st);
+    if constexpr (sizeof(T) == 2 && !DROP && DV == 96 && (DQK == 96 || DQK == 128 || DQK == 160)) {
+      if (attn_pipe_enabled(p, DQK)) return out_f32 ? launch_dkv_pipe<float, DQK, DV>(p, st) : launch_dkv_pipe<bf16_t, DQK, DV>(p, st);
     }
 #ifdef DCC_ATTN_KW2   // needs AGPR accumulators: build attention.hip without -amdgpu-mfma-vgpr-form
     if constexpr (sizeof(T) == 2 && !DROP) {

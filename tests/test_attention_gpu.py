@@ -35,6 +35,7 @@ CASES = [
     (1, 2, 1000, 200, 128, 96, False, True),
     (1, 1, 1030, 393, 160, 96, False, False),
     (1, 1, 801, 40, 128, 96, True, True),
+    (1, 2, 900, 300, 96, 96, False, False),   # the RoPE configuration's head width (no rel-pos columns)
 ]
 
 

@@ -10,7 +10,7 @@ def shapes(n, seed=1234):
     r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
     out = []
     for i in range(n):
-        dqk = (128, 160)[r(0, 1)]
+        dqk = (96, 128, 160)[r(0, 2)]
         out.append(dict(B=r(1, 2), H=r(1, 3), Nq=r(1, 1400) if i % 3 else r(1, 140), Nk=r(1, 450), DQK=dqk, DV=96, qsplit=(1, 1, 2, 3, 5)[r(0, 4)],
                         residual=bool(r(0, 1))))
     return out
