@@ -60,6 +60,9 @@ constexpr int ANT = 256;  // threads per block
 #ifndef DCC_ATTN_OCC_DKV
 #define DCC_ATTN_OCC_DKV 1
 #endif
+#ifndef DCC_ATTN_HAND_DQ
+#define DCC_ATTN_HAND_DQ 1
+#endif
 
 struct DropCtx {
   uint64_t seed; uint32_t thr; float inv_keep;
@@ -187,6 +190,61 @@ __device__ __forceinline__ frag_t<T> tr_frag(const char* lds, int t0, int s2, in
     }
   }
   return f;
+}
+
+// An inline-asm MFMA is opaque to the compiler's hazard recognizer: a vector instruction that writes one of its operands right in front
+// of it (a conversion that sank, an accumulator-register read-back of a parked K fragment, a zeroing move) needs wait states nobody
+// inserts — the MFMA then reads the register's previous contents.  Two wait states in front of every hand-written MFMA.
+#define PIPE_PRE "s_nop 1\n\t"
+#ifdef DCC_ATTN_PIPE_NOPS
+#define PIPE_NOPS "\n\ts_nop 15\n\ts_nop 3"
+#else
+#define PIPE_NOPS ""
+#endif
+// NB: __builtin_bit_cast applied directly to a vector ELEMENT (v[i]) reads element 0 whatever i is (hipcc 7.2): go through a scalar
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+// first MFMA of a chain: C = 0 as an inline constant.  (Zeroing the accumulator with vector moves and accumulating into it needs wait
+// states between the last move and the MFMA that the compiler cannot know to insert for an inline-asm MFMA: the MFMA then reads the
+// registers' previous contents.)
+__device__ __forceinline__ void mma16_vinit(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile(PIPE_PRE "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" PIPE_NOPS : "=&v"(acc) : "v"(a), "v"(b));
+}
+// ---- hand-placed pieces of the pipelined kernel's steady state (the compiler neither counts nor waits for these LDS reads)
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+template <int OFF> __device__ __forceinline__ u32x4 hlds_b128(uint32_t addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ u32x2 hlds_tr64(uint32_t addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// wait until at most N younger LDS operations are outstanding; the fragment is an operand so that its consumer stays behind the wait
+template <int N> __device__ __forceinline__ void hwait(u32x4& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
+// An MFMA chain whose LDS fragments are read AHEAD steps in front of their MFMA (hand-issued reads, counted waits): what hipcc emits
+// for `acc = mma16(frag_from_lds(k), b[k], acc)` is read -> wait -> MFMA with at most one read in flight, i.e. an LDS latency per MFMA.
+// issue(k) returns fragment k (OPS LDS operations each), mma(k, fragment) consumes it.
+template <int N, int OPS, typename Issue, typename Mma>
+__device__ __forceinline__ void hand_chain(Issue&& issue, Mma&& mma) {
+  constexpr int AHEAD = 3;
+  u32x4 fr[AHEAD + 1];
+  static_for<(N < AHEAD ? N : AHEAD)>([&](auto kc) { fr[decltype(kc)::value % (AHEAD + 1)] = issue(kc); });
+  static_for<N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int left = N - 1 - k;
+    hwait<OPS * (left < AHEAD - 1 ? left : AHEAD - 1)>(fr[k % (AHEAD + 1)]);
+    if constexpr (k + AHEAD < N) fr[(k + AHEAD) % (AHEAD + 1)] = issue(std::integral_constant<int, k + AHEAD>{});
+    mma(kc, __builtin_bit_cast(bf16x8, fr[k % (AHEAD + 1)]));
+    __builtin_amdgcn_sched_barrier(0);
+  });
 }
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
@@ -388,6 +446,7 @@ template <typename T, int DQK, int DV, bool DROP>
 __global__ __launch_bounds__(ANT, (DQK >= 160 && sizeof(T) == 2 && !DROP ? 2 : DCC_ATTN_OCC_DQ)) void attn_bwd_dq_kernel(AttnParams p) {
   using KT = RowTile<T, DQK>;
   using VT = RowTile<T, DV>;
+  constexpr bool HANDQ = DCC_ATTN_HAND_DQ && sizeof(T) == 2 && !DROP && DQK >= 128;   // MFMA chains with their LDS reads three steps ahead (-1 %; +0.6 % at DQK = 96: off there)
   __shared__ __attribute__((aligned(16))) char smem[TK * KT::PITCH + TK * VT::PITCH + TK * 4];
   char* ldsK = smem;
   char* ldsV = smem + TK * KT::PITCH;
@@ -469,10 +528,19 @@ __global__ __launch_bounds__(ANT, (DQK >= 160 && sizeof(T) == 2 && !DROP ? 2 : D
       f32x16 S, dP;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { S[e] = 0.0f; dP[e] = 0.0f; }
+      if constexpr (HANDQ) {
+        const uint32_t aK = (uint32_t)(uintptr_t)LDS_PTR(const char, ldsK) + (32 * sub + (lane & 31)) * KT::PITCH + 16 * h;
+        const uint32_t aV = (uint32_t)(uintptr_t)LDS_PTR(const char, ldsV) + (32 * sub + (lane & 31)) * VT::PITCH + 16 * h;
+        hand_chain<DQK / 16, 1>([&](auto sc) { return hlds_b128<32 * decltype(sc)::value>(aK); },
+                                [&](auto sc, const bf16x8& a) { S = mma16(a, qf[decltype(sc)::value], S); });
+        hand_chain<DV / 16, 1>([&](auto sc) { return hlds_b128<32 * decltype(sc)::value>(aV); },
+                               [&](auto sc, const bf16x8& a) { dP = mma16(a, dof[decltype(sc)::value], dP); });
+      } else {
 #pragma unroll
-      for (int s = 0; s < DQK / 16; ++s) S = mma16(row_frag<T, DQK>(ldsK, 32 * sub, s, lane), qf[s], S);
+        for (int s = 0; s < DQK / 16; ++s) S = mma16(row_frag<T, DQK>(ldsK, 32 * sub, s, lane), qf[s], S);
 #pragma unroll
-      for (int s = 0; s < DV / 16; ++s) dP = mma16(row_frag<T, DV>(ldsV, 32 * sub, s, lane), dof[s], dP);
+        for (int s = 0; s < DV / 16; ++s) dP = mma16(row_frag<T, DV>(ldsV, 32 * sub, s, lane), dof[s], dP);
+      }
       if constexpr (DROP) {  // dP = keep/(1-p) * (dO V^T)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dP[e] *= dc.mul(drow, (uint32_t)(kt0 + 32 * sub + acc_row(e, h)));
@@ -488,12 +556,30 @@ __global__ __launch_bounds__(ANT, (DQK >= 160 && sizeof(T) == 2 && !DROP ? 2 : D
           S[e] = pr * (dP[e] - dv);  // dz^T
         }
       }
+      if constexpr (HANDQ) {
+        const frag_t<T> zf2[2] = {acc_as_frag<T>(S, 0), acc_as_frag<T>(S, 1)};
+        const int i16 = lane & 15;
+        const uint32_t trK = (uint32_t)(uintptr_t)LDS_PTR(const char, ldsK) + (32 * sub + 4 * h + (i16 >> 2)) * KT::PITCH +
+                             (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
+        constexpr int NT = DQK / 32;
+        hand_chain<2 * NT, 2>(
+            [&](auto kc) {
+              constexpr int k = decltype(kc)::value, s2 = k / NT, t = k % NT;
+              const u32x2 lo = hlds_tr64<(16 * s2) * KT::PITCH + 64 * t>(trK), hi = hlds_tr64<(16 * s2 + 8) * KT::PITCH + 64 * t>(trK);
+              return u32x4{lo[0], lo[1], hi[0], hi[1]};
+            },
+            [&](auto kc, const bf16x8& a) {
+              constexpr int k = decltype(kc)::value;
+              dq[k % NT] = mma16(a, zf2[k / NT], dq[k % NT]);
+            });
+      } else {
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const frag_t<T> zf = acc_as_frag<T>(S, s2);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const frag_t<T> zf = acc_as_frag<T>(S, s2);
 #pragma unroll
-        for (int t = 0; t < DQK / 32; ++t)
-          dq[t] = mma16(tr_frag<T, DQK>(ldsK, 32 * sub, s2, 32 * t, lane), zf, dq[t]);
+          for (int t = 0; t < DQK / 32; ++t)
+            dq[t] = mma16(tr_frag<T, DQK>(ldsK, 32 * sub, s2, 32 * t, lane), zf, dq[t]);
+        }
       }
     }
   }
@@ -601,6 +687,15 @@ __global__ __launch_bounds__(ANT, (KW > 1 ? 1 : DCC_ATTN_OCC_DKV)) void attn_bwd
 #pragma unroll
         for (int e = 0; e < 16; ++e) { S[kw][e] = 0.0f; dP[kw][e] = 0.0f; }
       const bool two = KW > 1 && (k0 + 32 < p.Nk);  // the second key tile holds valid keys (wave-uniform)
+      constexpr bool HANDKV = DCC_ATTN_HAND_DQ && KW == 1 && sizeof(T) == 2 && !DROP && DQK >= 128;   // LDS fragments three MFMAs ahead (hand_chain)
+      if constexpr (HANDKV) {
+        const uint32_t aQ = (uint32_t)(uintptr_t)LDS_PTR(const char, ldsQ) + (32 * sub + (lane & 31)) * QT::PITCH + 16 * h;
+        const uint32_t aO = (uint32_t)(uintptr_t)LDS_PTR(const char, ldsO) + (32 * sub + (lane & 31)) * OT::PITCH + 16 * h;
+        hand_chain<DQK / 16, 1>([&](auto sc) { return hlds_b128<32 * decltype(sc)::value>(aQ); },
+                                [&](auto sc, const bf16x8& a) { S[0] = mma16(a, kf[0][decltype(sc)::value], S[0]); });
+        hand_chain<DV / 16, 1>([&](auto sc) { return hlds_b128<32 * decltype(sc)::value>(aO); },
+                               [&](auto sc, const bf16x8& a) { dP[0] = mma16(a, vf[0][decltype(sc)::value], dP[0]); });
+      } else {
 #pragma unroll
       for (int s = 0; s < DQK / 16; ++s) {
         const frag_t<T> a = row_frag<T, DQK>(ldsQ, 32 * sub, s, lane);
@@ -612,6 +707,7 @@ __global__ __launch_bounds__(ANT, (KW > 1 ? 1 : DCC_ATTN_OCC_DKV)) void attn_bwd
         const frag_t<T> a = row_frag<T, DV>(ldsO, 32 * sub, s, lane);
         dP[0] = mma16(a, vf[0][s], dP[0]);
         if constexpr (KW > 1) { if (two) dP[KW - 1] = mma16(a, vf[KW - 1][s], dP[KW - 1]); }
+      }
       }
       // rows = queries, lanes = keys
 #pragma unroll
@@ -631,6 +727,29 @@ __global__ __launch_bounds__(ANT, (KW > 1 ? 1 : DCC_ATTN_OCC_DKV)) void attn_bwd
           }
         }
       }
+      if constexpr (HANDKV) {
+        const frag_t<T> pf2[2] = {acc_as_frag<T>(S[0], 0), acc_as_frag<T>(S[0], 1)};
+        const frag_t<T> zf2[2] = {acc_as_frag<T>(dP[0], 0), acc_as_frag<T>(dP[0], 1)};
+        const int i16 = lane & 15;
+        const uint32_t lrow = 32 * sub + 4 * h + (i16 >> 2), lcol = (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
+        const uint32_t trO = (uint32_t)(uintptr_t)LDS_PTR(const char, ldsO) + lrow * OT::PITCH + lcol;
+        const uint32_t trQ = (uint32_t)(uintptr_t)LDS_PTR(const char, ldsQ) + lrow * QT::PITCH + lcol;
+        constexpr int NV = DV / 32, NQ = DQK / 32;
+        hand_chain<2 * NV, 2>(
+            [&](auto kc) {
+              constexpr int k = decltype(kc)::value, s2 = k / NV, t = k % NV;
+              const u32x2 lo = hlds_tr64<(16 * s2) * OT::PITCH + 64 * t>(trO), hi = hlds_tr64<(16 * s2 + 8) * OT::PITCH + 64 * t>(trO);
+              return u32x4{lo[0], lo[1], hi[0], hi[1]};
+            },
+            [&](auto kc, const bf16x8& a) { constexpr int k = decltype(kc)::value; dvv[0][k % NV] = mma16(a, pf2[k / NV], dvv[0][k % NV]); });
+        hand_chain<2 * NQ, 2>(
+            [&](auto kc) {
+              constexpr int k = decltype(kc)::value, s2 = k / NQ, t = k % NQ;
+              const u32x2 lo = hlds_tr64<(16 * s2) * QT::PITCH + 64 * t>(trQ), hi = hlds_tr64<(16 * s2 + 8) * QT::PITCH + 64 * t>(trQ);
+              return u32x4{lo[0], lo[1], hi[0], hi[1]};
+            },
+            [&](auto kc, const bf16x8& a) { constexpr int k = decltype(kc)::value; dk[0][k % NQ] = mma16(a, zf2[k / NQ], dk[0][k % NQ]); });
+      } else {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         frag_t<T> pf[KW], zf[KW];
@@ -648,6 +767,7 @@ __global__ __launch_bounds__(ANT, (KW > 1 ? 1 : DCC_ATTN_OCC_DKV)) void attn_bwd
           dk[0][t] = mma16(a, zf[0], dk[0][t]);
           if constexpr (KW > 1) { if (two) dk[KW - 1][t] = mma16(a, zf[KW - 1], dk[KW - 1][t]); }
         }
+      }
       }
     }
   }
@@ -736,15 +856,6 @@ template <int N, int NDS, int NVALU> __device__ __forceinline__ void sched_slots
 #ifndef PIPE_VALU_A
 #define PIPE_VALU_A 3
 #endif
-// An inline-asm MFMA is opaque to the compiler's hazard recognizer: a vector instruction that writes one of its operands right in front
-// of it (a conversion that sank, an accumulator-register read-back of a parked K fragment, a zeroing move) needs wait states nobody
-// inserts — the MFMA then reads the register's previous contents.  Two wait states in front of every hand-written MFMA.
-#define PIPE_PRE "s_nop 1\n\t"
-#ifdef DCC_ATTN_PIPE_NOPS
-#define PIPE_NOPS "\n\ts_nop 15\n\ts_nop 3"
-#else
-#define PIPE_NOPS ""
-#endif
 // the same with the result retired when the statement ends: for the compiler-scheduled prologue / epilogue code, where the register
 // allocator may copy an accumulator tuple right behind the MFMA (it does not know the statement's latency)
 __device__ __forceinline__ void mma16_acc_retired(f32x16& acc, const bf16x8& a, const bf16x8& b) {
@@ -753,34 +864,6 @@ __device__ __forceinline__ void mma16_acc_retired(f32x16& acc, const bf16x8& a, 
 __device__ __forceinline__ void mma16_vacc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
   asm volatile(PIPE_PRE "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" PIPE_NOPS : "+v"(acc) : "v"(a), "v"(b));
 }
-// NB: __builtin_bit_cast applied directly to a vector ELEMENT (v[i]) reads element 0 whatever i is (hipcc 7.2): go through a scalar
-__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
-// first MFMA of a chain: C = 0 as an inline constant.  (Zeroing the accumulator with vector moves and accumulating into it needs wait
-// states between the last move and the MFMA that the compiler cannot know to insert for an inline-asm MFMA: the MFMA then reads the
-// registers' previous contents.)
-__device__ __forceinline__ void mma16_vinit(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile(PIPE_PRE "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" PIPE_NOPS : "=&v"(acc) : "v"(a), "v"(b));
-}
-// ---- hand-placed pieces of the pipelined kernel's steady state (the compiler neither counts nor waits for these LDS reads)
-template <int N, typename F, int I = 0>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<N, F, I + 1>(static_cast<F&&>(f));
-  }
-}
-template <int OFF> __device__ __forceinline__ u32x4 hlds_b128(uint32_t addr) {
-  u32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
-template <int OFF> __device__ __forceinline__ u32x2 hlds_tr64(uint32_t addr) {
-  u32x2 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
-// wait until at most N younger LDS operations are outstanding; the fragment is an operand so that its consumer stays behind the wait
-template <int N> __device__ __forceinline__ void hwait(u32x4& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
 // dK / dV accumulate in AGPRs: the kernel is built with MFMA results in VGPRs (the softmax reads S and dP), and 112 more VGPRs
 // of accumulators would leave no room for the second S / dP pair and the fragments in flight
 __device__ __forceinline__ void mma16_acc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
