@@ -595,9 +595,9 @@ __global__ __launch_bounds__(ANT, (DQK >= 160 && sizeof(T) == 2 && !DROP ? 2 : D
 // ------------------------------------------------------------------------------------------
 // dK/dV: keys on lanes (one wave = KW tiles of 32 keys, block = 128 KW keys), queries staged 64 rows at a time.
 // blockIdx.x = key block * qsplit + query split.
-// KW = 2: every Q / dO fragment read from LDS (row and transposed) feeds two MFMAs, which halves the LDS bytes per MFMA — with one
-// key tile per wave the kernel's LDS reads (14 b128 + 28 tr_b64 per 28 MFMAs) take as long as the MFMAs themselves.  The price is
-// the doubled accumulator / K,V fragment set: one wave per SIMD.
+// KW = 2 (experiment, only instantiated with -DDCC_ATTN_KW2 and without this file's -amdgpu-mfma-vgpr-form flag, which cannot place
+// its accumulators): every Q / dO fragment read from LDS feeds two MFMAs, halving the LDS bytes per MFMA, at the price of a doubled
+// accumulator / K,V fragment set — 420+ registers with spills in the loop at DQK = 128; never faster.  The shipped form is KW = 1.
 template <typename T, typename TO, int DQK, int DV, bool DROP, int KW>
 __global__ __launch_bounds__(ANT, (KW > 1 ? 1 : DCC_ATTN_OCC_DKV)) void attn_bwd_dkv_kernel(AttnParams p) {
   using QT = RowTile<T, DQK>;
