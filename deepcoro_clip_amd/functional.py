@@ -7,6 +7,7 @@ masters with cached bf16 shadows, weight/bias gradients come back in fp32.
 from __future__ import annotations
 
 import math
+import collections
 import os
 
 import torch
@@ -206,13 +207,33 @@ def zeros_f32(shape, device) -> torch.Tensor:
 # will adopt the buffer without touching it) runs on a side stream, filling the launch gaps and partial last waves of the
 # data-gradient chain; the main stream re-joins it in an end-of-backward engine callback.
 WGRAD_SIDE = False
-_WG = {"stream": None, "queued": False}
+_WG = {"stream": None, "queued": False, "held": collections.deque()}
 
 
 def _join_wgrad():
     _WG["queued"] = False
     if _WG["stream"] is not None:
         torch.cuda.current_stream().wait_stream(_WG["stream"])
+    _WG["held"].clear()
+
+
+def _hold_gradient(g2: torch.Tensor, ws) -> None:
+    """The incoming gradient a side-stream weight-gradient GEMM reads stays referenced until that GEMM has run.  Not for its memory
+    (record_stream covers that): autograd accumulates gradients that meet at a tensor IN PLACE when nobody else holds the buffer
+    (InputBuffer: use_count == 1) — on the main stream, possibly while the side stream is still reading that very gradient, e.g. the
+    one an add node hands to both its inputs (round 4: the study aggregator's out_proj weight gradient came out 77 % off).  A second
+    reference makes autograd allocate the sum instead.  Released as soon as the GEMM's event has fired (checked at the next launch),
+    so only the few gradients the side stream is behind by stay alive; the OUTPUT is never held — AccumulateGrad adopts a gradient
+    buffer only while it is the sole owner."""
+    held = _WG["held"]
+    if torch.cuda.is_current_stream_capturing():  # HIP-graph capture of the step: events cannot be queried; held until the join
+        held.append((None, g2))
+        return
+    while held and held[0][0] is not None and held[0][0].query():
+        held.popleft()
+    ev = torch.cuda.Event()
+    ev.record(ws)
+    held.append((ev, g2))
 
 
 def side_param_work(fn, *tensors) -> bool:
@@ -271,6 +292,7 @@ def wgrad(g2: torch.Tensor, x2: torch.Tensor, colsum: torch.Tensor | None = None
     K.gemm(g2, x2, a_km=True, b_km=True, out=out, accumulate=sk > 1, splitk=sk, colsum=colsum, stream=ws.cuda_stream)
     g2.record_stream(ws)
     x2.record_stream(ws)
+    _hold_gradient(g2, ws)
     return out
 
 
