@@ -125,10 +125,11 @@ class VideoContrastiveLearningRunner:
         self._graphs: dict = {}
         self._dropout_step: torch.Tensor | None = None
         self._autograd_mt = os.environ.get("DCC_AUTOGRAD_MT", "0") == "1"  # backward on the engine's device thread
-        # weight-gradient GEMMs on the parameter-gradient side stream (one rank, no accumulation: functional.wgrad).  Off in rounds
-        # 1-3, when the host's launch time was the limit (+5 ms of enqueue for what it hid); with the host at 27-30 ms against 40 ms
-        # of GPU time it is worth -1.5 ms per step (round 4, alternating on one box: 42.41 / 41.99 without, 40.61 / 40.46 with)
-        self._wgrad_side = os.environ.get("DCC_WGRAD_STREAM", "1") == "1"
+        # weight-gradient GEMMs on the parameter-gradient side stream (one rank, no accumulation: functional.wgrad).  Round 4
+        # re-measured it (and fixed the in-place-accumulation race it had): -1.4 ms per step on three boxes, +1.3 ms on two others,
+        # where the host becomes the limit (every side launch costs two event operations; enqueue time inside the timed region
+        # 36.7 -> 40.5 ms against 40.7 ms of GPU time).  Off by default; DCC_WGRAD_STREAM=1 turns it on.
+        self._wgrad_side = os.environ.get("DCC_WGRAD_STREAM", "0") == "1"
         self._graph_stream: torch.cuda.Stream | None = None
         self._cache_check = os.environ.get("DCC_CACHE_CHECK", "0") == "1"
         # host -> device copies of batch i+1 on their own stream while step i runs (config.prefetch_batches, default on): the
